@@ -1,0 +1,214 @@
+"""CPU tests: the oracle (oracle/snappy_oracle.c) against every pin we have.
+
+  * the sizes the reference itself publishes (benchmark/sw_results.csv)
+  * byte-level goldens generated from libsnappy 1.1.8 (tests/golden/make_golden.py)
+  * libsnappy 1.1.8 itself when it is present on this machine (differential fuzz)
+  * the element encodings of the reference's RTL unit test (CopyCompressSpec.scala:99-107)
+"""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fuzzgen
+import oracle_lib
+import snappy_format
+
+G = fuzzgen.GOLDEN_DIR
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def _input_for(name):
+    mtg = fuzzgen.corpus("mtg")
+    fox = fuzzgen.corpus("fox")
+    rnd = fuzzgen.corpus("random_ascii")
+    if name == "thistle":
+        return (b"If Tid the thistle sifter lifts his sieve of sifted thistles, then he'll shift "
+                b"the thistles in his sifting sieve to live unsifted.")
+    if name == "fox-in-socks.txt":
+        return fox
+    if name == "randomASCII.txt":
+        return rnd
+    if name == "all-mtg-cards.txt":
+        return mtg
+    if name.startswith("benchmark-data/"):
+        with open(os.path.join(fuzzgen.DATA_DIR, name), "rb") as f:
+            return f.read()
+    if name == "mtg[0:4096]x16":
+        return mtg[:4096] * 16
+    if name == "fox[0:4096]x16":
+        return fox[:4096] * 16
+    if name == "randomASCII[0:4096]x16":
+        return rnd[:4096] * 16
+    if name.startswith("randomASCII tiled block "):
+        return fuzzgen.tiled_block(rnd, int(name.split()[-1]))
+    raise KeyError(name)
+
+
+with open(os.path.join(G, "golden_files.json")) as f:
+    GOLDEN_FILES = json.load(f)["files"]
+with open(os.path.join(G, "golden_fuzz.json")) as f:
+    GOLDEN_FUZZ = json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("entry", GOLDEN_FILES, ids=[e["name"] for e in GOLDEN_FILES])
+def test_oracle_matches_file_goldens(entry):
+    data = _input_for(entry["name"])
+    assert len(data) == entry["in_len"] and sha(data) == entry["in_sha256"]
+    out = oracle_lib.raw_compress(data)
+    assert len(out) == entry["out_len"]
+    assert sha(out) == entry["out_sha256"]
+    assert "%016x" % oracle_lib.fnv1a64(out) == entry["out_fnv1a64"]
+    if "out_hex" in entry:
+        assert out.hex() == entry["out_hex"]
+    assert oracle_lib.uncompress(out) == data
+    for k, b in enumerate(entry.get("blocks", [])):
+        blk = data[k * 65536:(k + 1) * 65536]
+        o = oracle_lib.raw_compress(blk)
+        assert (len(o), sha(o)) == (b["out_len"], b["out_sha256"]), "block %d" % k
+
+
+def test_oracle_matches_fuzz_goldens():
+    bad = []
+    for c in GOLDEN_FUZZ:
+        data = fuzzgen.gen(c["kind"], c["seed"], c["n"])
+        out = oracle_lib.raw_compress(data)
+        if len(out) != c["out_len"] or sha(out) != c["out_sha256"]:
+            bad.append((c["kind"], c["seed"], c["n"]))
+    assert not bad, bad[:10]
+
+
+def test_oracle_roundtrip_fuzz_sample():
+    for c in GOLDEN_FUZZ[::7]:
+        data = fuzzgen.gen(c["kind"], c["seed"], c["n"]).tobytes()
+        assert oracle_lib.uncompress(oracle_lib.raw_compress(data)) == data
+
+
+def test_sizes_pinned_by_reference_csv():
+    """benchmark/sw_results.csv compressed-length column.  33 of 36 rows are reproduced
+    exactly; real-10000/20000/50000 differ by 2/3/3 bytes for libsnappy 1.1.8 itself too
+    (those inputs hold control bytes and went through bash argv in
+    the reference harness)."""
+    with open(os.path.join(G, "sw_results_sizes.json")) as f:
+        pins = json.load(f)
+    known_delta = {("real", 10000): 3740, ("real", 20000): 8177, ("real", 50000): 20792}
+    exact = 0
+    for row in pins["rows"]:
+        prefix = pins["file_prefix"][row["type"]]
+        with open(os.path.join(fuzzgen.DATA_DIR, "benchmark-data", "%s-%d.txt" % (prefix, row["length"])), "rb") as f:
+            data = f.read()
+        assert len(data) == row["length"]
+        got = len(oracle_lib.raw_compress(data))
+        key = (row["type"], row["length"])
+        if key in known_delta:
+            assert got == known_delta[key] and 0 < row["compressed_length"] - got <= 3
+        else:
+            assert got == row["compressed_length"], key
+            exact += 1
+    assert exact == 33
+
+
+def test_thistle_and_repeating_a_from_reference_drivers():
+    # tests/compression.c:43 sentence -> 112 bytes; tests/swcompression.cc:8 uses a run of 'a'
+    out = oracle_lib.raw_compress(_input_for("thistle"))
+    assert len(out) == 112 and out[:2] == bytes([0x82, 0x01])
+    a = b"a" * 700
+    o = oracle_lib.raw_compress(a)
+    assert oracle_lib.uncompress(o) == a
+    # literal 'a', then one copy of 699 at offset 1: 10 x 64-byte elements + 59
+    assert o[:2] == bytes([0xBC, 0x05]) and o[2:4] == bytes([0x00, ord("a")])
+    assert o[4:7] == bytes([2 | (63 << 2), 1, 0])
+
+
+def test_copy_element_layout_matches_rtl_goldens():
+    """Every copy element the oracle emits must carry exactly the bytes of the RTL unit
+    test's golden formulas (CopyCompressSpec.scala:99-107; encoder CopyCompress.scala:236-250).
+    The RTL packs the tag byte in the high byte of its output word; compared per byte."""
+    seen_short = seen_long = 0
+    for kind, seed in (("lz", 5), ("words", 6), ("text_mtg", 7), ("periodic", 8), ("runs", 9), ("alpha4", 10)):
+        data = fuzzgen.gen(kind, seed, 65536).tobytes()
+        body = oracle_lib.compress_fragment(data)
+        for k, pos, ln, off, raw in snappy_format.elements(body):
+            if k != "copy":
+                continue
+            assert 4 <= ln <= 64 and 1 <= off <= pos
+            if ln <= 11 and off < 2048:
+                golden = (off & 0xFF) | ((off & 0x700) << 5) | ((ln - 4) << 10) | (1 << 8)
+                assert raw == bytes([(golden >> 8) & 0xFF, golden & 0xFF])
+                seen_short += 1
+            else:
+                golden = ((off & 0xFF00) >> 8) | ((off & 0x00FF) << 8) | ((ln - 1) << 18) | (2 << 16)
+                assert raw == bytes([(golden >> 16) & 0xFF, (golden >> 8) & 0xFF, golden & 0xFF])
+                seen_long += 1
+    assert seen_short > 1000 and seen_long > 1000
+
+
+def test_match_finder_kat_aligner_data():
+    """data/alignerTestData.txt is the RTL match-finder KAT (MatchFinderTester.scala:53-57):
+    4-byte repeats planted at 45<->1, 57<->20, 70<->16 (the RTL has a 512-entry table and
+    probes every byte).  Software Snappy on 96 bytes uses a 256-entry table and inserts only
+    probed positions, so it may miss a planted repeat, but every copy it takes must be one
+    of the planted pairs and the first one must be found."""
+    rows = open(os.path.join(fuzzgen.DATA_DIR, "alignerTestData.txt")).read().split()
+    data = b"".join(bytes.fromhex(r) for r in rows)[:96]
+    body = oracle_lib.compress_fragment(data)
+    copies = [(pos, pos - off) for k, pos, ln, off, raw in snappy_format.elements(body) if k == "copy"]
+    planted = {(45, 1), (57, 20), (70, 16)}
+    for p, c in planted:
+        assert data[p:p + 4] == data[c:c + 4]
+    assert copies and copies[0] == (45, 1) and set(copies) <= planted, copies
+
+
+def test_java_lcg_regenerates_random_ascii_fixture():
+    # DataGenerator.scala:13-16 -- Random(4444).nextInt(93)+32, 100000 bytes
+    want = fuzzgen.corpus("random_ascii")
+    got = fuzzgen.java_random_ascii(len(want))
+    assert got[:16] == b"Z*%r)I*cG9FtPNP]"
+    assert got == want
+
+
+LIBSNAPPY = "/opt/conda/lib/libsnappy.so.1.1.8"
+
+
+@pytest.mark.skipif(not os.path.exists(LIBSNAPPY), reason="libsnappy 1.1.8 not on this machine")
+def test_oracle_differential_vs_libsnappy_1_1_8():
+    lib = ctypes.CDLL(LIBSNAPPY)
+    lib.snappy_compress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
+    lib.snappy_max_compressed_length.restype = ctypes.c_size_t
+    lib.snappy_max_compressed_length.argtypes = [ctypes.c_size_t]
+    rs = np.random.RandomState(77)
+    for i in range(1500):
+        kind = fuzzgen.KINDS[int(rs.randint(0, len(fuzzgen.KINDS)))]
+        n = int(rs.randint(0, 3000)) if i % 5 else int(rs.randint(0, 140000))
+        data = fuzzgen.gen(kind, 100000 + i, n).tobytes()
+        cap = lib.snappy_max_compressed_length(n)
+        buf = ctypes.create_string_buffer(cap)
+        k = ctypes.c_size_t(cap)
+        assert lib.snappy_compress(data, n, buf, ctypes.byref(k)) == 0
+        assert oracle_lib.raw_compress(data) == buf.raw[:k.value], (kind, 100000 + i, n)
+
+
+def test_oracle_batch_form_and_threads():
+    rnd = fuzzgen.corpus("mtg")[:65536 * 5 + 1234]
+    nb = 6
+    in_len = np.array([65536] * 5 + [1234], dtype=np.uint32)
+    pad = np.zeros(nb * 65536, dtype=np.uint8)
+    pad[:len(rnd)] = np.frombuffer(rnd, dtype=np.uint8)
+    for threads in (1, 3):
+        dst, out_len = oracle_lib.compress_blocks(pad, 65536, nb, in_len=in_len, threads=threads)
+        for b in range(nb):
+            want = oracle_lib.raw_compress(rnd[b * 65536:(b + 1) * 65536])
+            assert dst[b, :out_len[b]].tobytes() == want
+
+
+def test_oracle_rejects_malformed_streams():
+    good = oracle_lib.raw_compress(b"hello hello hello hello hello hello")
+    for bad in (good[:-1], good[:3], b"\xff\xff\xff\xff\xff\xff", good[:1] + b"\x05\x00\x10"):
+        with pytest.raises(ValueError):
+            oracle_lib.uncompress(bad)
