@@ -1,0 +1,355 @@
+// snappy_abi.cpp -- the C ABI of include/snappy_hip.h over the gfx950 kernels.
+//
+// Host side of the drop-in boundary.  Mirrors, for the one hot path, the call surfaces of the
+// reference: the RoCC command port driven by tests/compression.c:20-39 (decoded in
+// CompressionAccelerator.scala:54-73,361-389) and snappy::Compress / snappy::Uncompress as called
+// by tests/swcompression.cc:27,31,45.  There is NO CPU compression path in this library: every
+// compute entry point runs the HIP kernels or fails with SZ_ENODEV / SZ_EHIP.
+#include "snappy_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "snappy_kernels.h"
+
+namespace {
+
+thread_local int tl_hip_error = 0;
+thread_local int tl_rocc_error = 0;
+thread_local uint32_t tl_rocc_length = 0;  // the accelerator's latched `length` register
+
+inline int hip_fail(hipError_t e)
+{
+    tl_hip_error = (int)e;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+        return SZ_ENODEV;
+    return SZ_EHIP;
+}
+#define SZ_HIP(call)                   \
+    do {                               \
+        hipError_t e_ = (call);        \
+        if (e_ != hipSuccess)          \
+            return hip_fail(e_);       \
+    } while (0)
+
+// Grow-only device workspace of the host-buffer API, one per host thread (one RoCC port per hart).
+struct Workspace {
+    hipStream_t stream = nullptr;
+    void *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[5] = {0, 0, 0, 0, 0};
+    int device = -1;
+
+    int ensure_stream()
+    {
+        int dev = 0;
+        SZ_HIP(hipGetDevice(&dev));
+        if (stream && dev != device)
+            release();
+        if (!stream) {
+            SZ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            device = dev;
+        }
+        return SZ_OK;
+    }
+    int reserve(int i, size_t bytes)
+    {
+        if (bytes <= cap[i])
+            return SZ_OK;
+        if (buf[i]) {
+            (void)hipFree(buf[i]);
+            buf[i] = nullptr;
+            cap[i] = 0;
+        }
+        size_t want = bytes + bytes / 4 + 4096;
+        SZ_HIP(hipMalloc(&buf[i], want));
+        cap[i] = want;
+        return SZ_OK;
+    }
+    void release()
+    {
+        for (int i = 0; i < 5; i++) {
+            if (buf[i])
+                (void)hipFree(buf[i]);
+            buf[i] = nullptr;
+            cap[i] = 0;
+        }
+        if (stream)
+            (void)hipStreamDestroy(stream);
+        stream = nullptr;
+        device = -1;
+    }
+};
+thread_local Workspace tl_ws;  // deliberately not freed at thread exit (HIP may be gone by then)
+
+size_t put_varint32(uint8_t *dst, uint32_t v)
+{
+    size_t k = 0;
+    while (v >= 0x80) {
+        dst[k++] = (uint8_t)(v | 0x80);
+        v >>= 7;
+    }
+    dst[k++] = (uint8_t)v;
+    return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sz_max_compressed_length(size_t n) { return 32 + n + n / 6; }
+
+int sz_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        tl_hip_error = (int)e;
+        return 0;
+    }
+    return n;
+}
+
+int sz_last_hip_error(void) { return tl_hip_error; }
+
+const char *sz_version(void) { return "snappy_hip 0.1 (gfx950; Snappy 1.1.8 bit-exact)"; }
+
+const char *sz_strerror(int code)
+{
+    switch (code) {
+    case SZ_OK: return "ok";
+    case SZ_EINVAL: return "invalid argument";
+    case SZ_ENOSPC: return "destination too small";
+    case SZ_EHIP: return "HIP runtime error";
+    case SZ_ENODEV: return "no usable GPU";
+    case SZ_ECORRUPT: return "malformed Snappy stream";
+    default: return "unknown error";
+    }
+}
+
+void sz_release_thread_resources(void) { tl_ws.release(); }
+
+/* ------------------------------------------------------------------ device-resident API */
+
+int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *d_in_len,
+                           uint32_t n_blocks, void *d_dst, size_t dst_stride, uint32_t *d_out_len,
+                           uint32_t flags, void *stream)
+{
+    if (n_blocks == 0)
+        return SZ_OK;
+    if (!d_src || !d_dst || !d_out_len || (flags & ~SZ_FLAG_BLOCK_VARINT))
+        return SZ_EINVAL;
+    if (in_stride == 0 || (!d_in_len && in_stride > SZ_BLOCK_SIZE))
+        return SZ_EINVAL;
+    // with explicit lengths the host cannot see them; a block never exceeds min(in_stride, 64 KiB)
+    const size_t longest = in_stride < SZ_BLOCK_SIZE ? in_stride : SZ_BLOCK_SIZE;
+    if (dst_stride < sz_max_compressed_length(longest) + 5)
+        return SZ_ENOSPC;
+    SZ_HIP(szk::launch_compress_blocks(d_src, in_stride, d_in_len, n_blocks, d_dst, dst_stride, d_out_len,
+                                       flags, static_cast<hipStream_t>(stream)));
+    return SZ_OK;
+}
+
+int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t slot_stride,
+                           uint32_t *d_len, uint32_t flags, void *stream)
+{
+    if (n == 0)
+        return SZ_OK;
+    if (!d_src || !d_slots || !d_len || n > 0xffffffffull || (flags & ~SZ_FLAG_BLOCK_VARINT))
+        return SZ_EINVAL;
+    const size_t longest = n < SZ_BLOCK_SIZE ? n : SZ_BLOCK_SIZE;
+    if (slot_stride < sz_max_compressed_length(longest) + 5)
+        return SZ_ENOSPC;
+    SZ_HIP(szk::launch_compress_stream(d_src, n, d_slots, slot_stride, d_len, flags,
+                                       static_cast<hipStream_t>(stream)));
+    return SZ_OK;
+}
+
+int sz_pack_stream_hip(const void *d_slots, size_t slot_stride, const uint32_t *d_len,
+                       uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off, void *stream)
+{
+    if (!d_off || (n_blocks && (!d_slots || !d_len || !d_packed)))
+        return SZ_EINVAL;
+    SZ_HIP(szk::launch_pack_stream(d_slots, slot_stride, d_len, n_blocks, base, d_packed, d_off,
+                                   static_cast<hipStream_t>(stream)));
+    return SZ_OK;
+}
+
+int sz_uncompress_blocks_hip(const void *d_src, size_t src_stride, const uint32_t *d_src_len,
+                             uint32_t n_streams, void *d_dst, size_t dst_stride, uint32_t *d_out_len,
+                             int32_t *d_status, void *stream)
+{
+    if (n_streams == 0)
+        return SZ_OK;
+    if (!d_src || !d_src_len || !d_dst || !d_out_len || !d_status)
+        return SZ_EINVAL;
+    SZ_HIP(szk::launch_uncompress_streams(d_src, src_stride, d_src_len, n_streams, d_dst, dst_stride,
+                                          d_out_len, d_status, static_cast<hipStream_t>(stream)));
+    return SZ_OK;
+}
+
+/* --------------------------------------------------------------------- host-buffer API */
+
+int sz_get_uncompressed_length(const void *src, size_t n, size_t *result)
+{
+    if (!src || !result)
+        return SZ_EINVAL;
+    const uint8_t *p = static_cast<const uint8_t *>(src);
+    uint32_t v = 0;
+    for (size_t i = 0; i < 5 && i < n; i++) {
+        uint32_t b = p[i];
+        if (i == 4 && b > 0x0f)
+            return SZ_ECORRUPT;
+        v |= (b & 0x7f) << (7 * i);
+        if (b < 0x80) {
+            *result = v;
+            return SZ_OK;
+        }
+    }
+    return SZ_ECORRUPT;
+}
+
+int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len)
+{
+    if (!dst || !out_len || (n && !src) || n > 0xffffffffull)
+        return SZ_EINVAL;
+    uint8_t hdr[5];
+    const size_t nh = put_varint32(hdr, (uint32_t)n);
+    if (dst_cap < nh)
+        return SZ_ENOSPC;
+    if (sz_device_count() < 1)  // fail loudly: there is no CPU fallback
+        return SZ_ENODEV;
+    memcpy(dst, hdr, nh);
+    if (n == 0) {
+        *out_len = nh;
+        return SZ_OK;
+    }
+    Workspace &ws = tl_ws;
+    int rc = ws.ensure_stream();
+    if (rc)
+        return rc;
+    const uint32_t nb = (uint32_t)((n + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
+    const size_t stride = SZ_SLOT_STRIDE;
+    if ((rc = ws.reserve(0, n)) || (rc = ws.reserve(1, (size_t)nb * stride)) ||
+        (rc = ws.reserve(2, (size_t)nb * sizeof(uint32_t))) ||
+        (rc = ws.reserve(3, ((size_t)nb + 1) * sizeof(uint64_t))) ||
+        (rc = ws.reserve(4, sz_max_compressed_length(n) + 16)))
+        return rc;
+    uint8_t *d_in = static_cast<uint8_t *>(ws.buf[0]);
+    uint8_t *d_slots = static_cast<uint8_t *>(ws.buf[1]);
+    uint32_t *d_len = static_cast<uint32_t *>(ws.buf[2]);
+    uint64_t *d_off = static_cast<uint64_t *>(ws.buf[3]);
+    uint8_t *d_packed = static_cast<uint8_t *>(ws.buf[4]);
+    SZ_HIP(hipMemcpyAsync(d_in, src, n, hipMemcpyHostToDevice, ws.stream));
+    if ((rc = sz_compress_stream_hip(d_in, n, d_slots, stride, d_len, 0, ws.stream)))
+        return rc;
+    if ((rc = sz_pack_stream_hip(d_slots, stride, d_len, nb, nh, d_packed, d_off, ws.stream)))
+        return rc;
+    uint64_t total = 0;
+    SZ_HIP(hipMemcpyAsync(&total, d_off + nb, sizeof(total), hipMemcpyDeviceToHost, ws.stream));
+    SZ_HIP(hipStreamSynchronize(ws.stream));
+    if (total > dst_cap)
+        return SZ_ENOSPC;
+    SZ_HIP(hipMemcpyAsync(static_cast<uint8_t *>(dst) + nh, d_packed + nh, total - nh,
+                          hipMemcpyDeviceToHost, ws.stream));
+    SZ_HIP(hipStreamSynchronize(ws.stream));
+    *out_len = (size_t)total;
+    return SZ_OK;
+}
+
+int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len)
+{
+    if (!src || !out_len || n == 0 || n > 0xffffffffull)
+        return n == 0 ? SZ_ECORRUPT : SZ_EINVAL;
+    size_t ulen = 0;
+    int rc = sz_get_uncompressed_length(src, n, &ulen);
+    if (rc)
+        return rc;
+    if (ulen > dst_cap || (ulen && !dst))
+        return SZ_ENOSPC;
+    if (sz_device_count() < 1)
+        return SZ_ENODEV;
+    Workspace &ws = tl_ws;
+    if ((rc = ws.ensure_stream()))
+        return rc;
+    if ((rc = ws.reserve(0, n)) || (rc = ws.reserve(1, ulen + 16)) || (rc = ws.reserve(2, 16)))
+        return rc;
+    uint8_t *d_in = static_cast<uint8_t *>(ws.buf[0]);
+    uint8_t *d_out = static_cast<uint8_t *>(ws.buf[1]);
+    uint32_t *d_meta = static_cast<uint32_t *>(ws.buf[2]);  // [0]=src_len [1]=out_len [2]=status
+    uint32_t meta[3] = {(uint32_t)n, 0, 0};
+    SZ_HIP(hipMemcpyAsync(d_in, src, n, hipMemcpyHostToDevice, ws.stream));
+    SZ_HIP(hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, ws.stream));
+    if ((rc = sz_uncompress_blocks_hip(d_in, n, d_meta, 1, d_out, ulen, d_meta + 1,
+                                       reinterpret_cast<int32_t *>(d_meta + 2), ws.stream)))
+        return rc;
+    SZ_HIP(hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, ws.stream));
+    SZ_HIP(hipStreamSynchronize(ws.stream));
+    if ((int32_t)meta[2] != 0)
+        return (int32_t)meta[2];
+    if (meta[1] != ulen)
+        return SZ_ECORRUPT;
+    if (ulen) {
+        SZ_HIP(hipMemcpyAsync(dst, d_out, ulen, hipMemcpyDeviceToHost, ws.stream));
+        SZ_HIP(hipStreamSynchronize(ws.stream));
+    }
+    *out_len = ulen;
+    return SZ_OK;
+}
+
+/* ------------------------------------------------------------------ RoCC command surface */
+
+int sz_rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2, uint64_t *rd)
+{
+    if (channel != SZ_ROCC_CHANNEL)  // the accelerator sits on custom3 only (Configs.scala:87-95)
+        return SZ_EINVAL;
+    switch (funct) {
+    case SZ_ROCC_SET_LENGTH:  // CompressionAccelerator.scala:363-364: length := rs1 (32 bit)
+        tl_rocc_length = (uint32_t)rs1;
+        if (rd)
+            *rd = 0;
+        return SZ_OK;
+    case SZ_ROCC_COMPRESS: {  // :365-384 + :405-407: rd := compressed length
+        size_t out = 0;
+        const size_t len = tl_rocc_length;
+        int rc = sz_compress(reinterpret_cast<const void *>(rs1), len, reinterpret_cast<void *>(rs2),
+                             sz_max_compressed_length(len), &out);
+        if (rc)
+            return rc;
+        if (rd)
+            *rd = out;
+        return SZ_OK;
+    }
+    case SZ_ROCC_UNCOMPRESS: {  // tests/compression.c:32-39: rd != 0 means failure
+        size_t ulen = 0, out = 0;
+        const void *src = reinterpret_cast<const void *>(rs1);
+        int rc = sz_get_uncompressed_length(src, tl_rocc_length, &ulen);
+        if (rc == SZ_OK)
+            rc = sz_uncompress(src, tl_rocc_length, reinterpret_cast<void *>(rs2), ulen, &out);
+        if (rc == SZ_ENODEV || rc == SZ_EHIP)
+            return rc;
+        if (rd)
+            *rd = rc == SZ_OK ? 0 : 1;
+        return SZ_OK;
+    }
+    default:
+        return SZ_EINVAL;
+    }
+}
+
+uint64_t rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2)
+{
+    uint64_t rd = 0;
+    int rc = sz_rocc_cmd(channel, funct, rs1, rs2, &rd);
+    tl_rocc_error = rc;
+    if (rc != SZ_OK) {
+        fprintf(stderr, "snappy_hip: RoCC command funct=%d failed: %s (hip error %d)\n", funct,
+                sz_strerror(rc), sz_last_hip_error());
+        return (uint64_t)-1;
+    }
+    return rd;
+}
+
+int sz_rocc_last_error(void) { return tl_rocc_error; }
+
+}  // extern "C"

@@ -1,0 +1,28 @@
+// snappy_kernels.h -- internal launch interface between the C ABI (snappy_abi.cpp) and the
+// gfx950 kernels (snappy_kernels.hip).  Not installed; the public boundary is include/snappy_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace szk {
+
+constexpr uint32_t kFlagBlockVarint = 1u;  // == SZ_FLAG_BLOCK_VARINT
+constexpr int32_t kStatusCorrupt = -74;    // == SZ_ECORRUPT
+constexpr int32_t kStatusNoSpace = -28;    // == SZ_ENOSPC
+
+hipError_t launch_compress_blocks(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len,
+                                  uint32_t n_blocks, void *d_dst, uint64_t dst_stride,
+                                  uint32_t *d_out_len, uint32_t flags, hipStream_t stream);
+
+hipError_t launch_compress_stream(const void *d_src, uint64_t n, void *d_slots, uint64_t slot_stride,
+                                  uint32_t *d_len, uint32_t flags, hipStream_t stream);
+
+hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const uint32_t *d_len,
+                              uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
+                              hipStream_t stream);
+
+hipError_t launch_uncompress_streams(const void *d_src, uint64_t src_stride, const uint32_t *d_src_len,
+                                     uint32_t n_streams, void *d_dst, uint64_t dst_stride,
+                                     uint32_t *d_out_len, int32_t *d_status, hipStream_t stream);
+
+}  // namespace szk

@@ -1,0 +1,590 @@
+// snappy_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the Snappy block compressor.
+//
+// Hot path: hash table (a2) + match finder (a3) + pointer advance (a4) +
+// match extension (a5) + copy element encoder (a6) + literal emission (a7) + preamble (a8) +
+// result length (a9).  Output is byte-identical to software Snappy 1.1.8 (the parity target of
+// the reference's tests/swcompression.cc:45), not to the RTL's own stream.
+//
+// Mapping to the machine
+//   * one 64-lane wavefront (= one 64-thread workgroup) per <=64 KiB block;
+//   * the 16384 x uint16 hash table lives in LDS (32 KiB -> 5 blocks resident per CU out of
+//     160 KiB; nothing else is kept in LDS so that the 5th wave fits);
+//   * the greedy parse is serial in the reference; here the SCAN phase is speculated 64 probes
+//     at a time: between two matches the probe schedule is a pure function of the miss count
+//     (skip starts at 32 and grows by skip>>5 per miss), so lane k probes the k-th future
+//     position, a ballot finds the first hit and the table is rolled back behind it;
+//   * match extension compares 64 B (then 1 KiB) per step with a ballot for the first
+//     mismatch; literal bytes and split copy elements are written by all lanes;
+//   * input is read with coalesced/unaligned global loads (L1/L2), output written once.
+//
+// No MFMA: this is byte/integer work bounded by HBM ("Roofline").
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "snappy_kernels.h"
+
+namespace szk {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
+static constexpr uint32_t kMaxBlock = 65536u;
+static constexpr uint32_t kMaxTable = 16384u;
+static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
+
+// Probe schedule of the scan loop after a (re)start: off[k] = distance of the k-th probe from the
+// first one.  skip_0 = 32, off_{k+1} = off_k + (skip_k >> 5), skip_{k+1} = skip_k + (skip_k >> 5).
+// 266 probes span 64 KiB; entries past that saturate so they always fail the limit check.
+static constexpr int kProbeEntries = 384;
+struct ProbeSchedule {
+    uint32_t off[kProbeEntries];
+};
+static constexpr ProbeSchedule make_probe_schedule()
+{
+    ProbeSchedule s{};
+    uint32_t skip = 32, pos = 0;
+    for (int k = 0; k < kProbeEntries; k++) {
+        s.off[k] = pos;
+        uint32_t step = skip >> 5;
+        skip += step;
+        pos += step;
+        if (pos > (1u << 20)) {
+            pos = 1u << 20;
+            skip = 32;
+        }
+    }
+    return s;
+}
+__device__ const ProbeSchedule g_probe = make_probe_schedule();
+
+// ------------------------------------------------------------------------------- helpers
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);  // gfx950: one (possibly unaligned) global_load_dword
+    return v;
+}
+__device__ __forceinline__ uint64_t ld64(const uint8_t *p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ u32x4 ld128(const uint8_t *p)
+{
+    u32x4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l)
+{
+    return __builtin_amdgcn_readlane(v, uni(l));
+}
+__device__ __forceinline__ uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
+
+// Cooperative byte copy by one wave, dst-aligned 16-byte stores in the bulk.
+__device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s,
+                                          uint32_t len, uint32_t lane)
+{
+    if (len <= 64) {
+        if (lane < len)
+            d[lane] = s[lane];
+        return;
+    }
+    uint32_t head = (16u - (uint32_t)((uintptr_t)d & 15u)) & 15u;
+    if (lane < head)
+        d[lane] = s[lane];
+    d += head;
+    s += head;
+    len -= head;
+    const uint32_t nvec = len >> 4;
+    uint32_t i = lane;
+    // 4 x 1 KiB in flight per step
+    for (; i + 192 < nvec; i += 256) {
+        u32x4 q0 = ld128(s + 16 * (size_t)i);
+        u32x4 q1 = ld128(s + 16 * (size_t)(i + 64));
+        u32x4 q2 = ld128(s + 16 * (size_t)(i + 128));
+        u32x4 q3 = ld128(s + 16 * (size_t)(i + 192));
+        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)i) = q0;
+        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)(i + 64)) = q1;
+        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)(i + 128)) = q2;
+        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)(i + 192)) = q3;
+    }
+    for (; i < nvec; i += 64)
+        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)i) = ld128(s + 16 * (size_t)i);
+    const uint32_t done = nvec << 4;
+    if (lane < (len & 15u))
+        d[done + lane] = s[done + lane];
+}
+
+// Literal element (a7): tag (len-1)<<2 for len<=60 (CompressionAccelerator.scala:172,231-233);
+// software Snappy tags 60/61 + 1/2 little-endian bytes of len-1 for longer runs (len<=65536).
+__device__ __forceinline__ uint32_t emit_literal(uint8_t *__restrict__ out, uint32_t op,
+                                                 const uint8_t *__restrict__ s, uint32_t len,
+                                                 uint32_t lane)
+{
+    const uint32_t v = len - 1;
+    uint32_t hdr, word;
+    if (v < 60) {
+        hdr = 1;
+        word = v << 2;
+    } else if (v < 256) {
+        hdr = 2;
+        word = (60u << 2) | (v << 8);
+    } else {
+        hdr = 3;
+        word = (61u << 2) | (v << 8);
+    }
+    if (lane < hdr)
+        out[op + lane] = (uint8_t)(word >> (8 * lane));
+    wave_copy(out + op + hdr, s, len, lane);
+    return op + hdr + len;
+}
+
+// Copy elements (a6), byte layouts of CopyStreamFormer (CopyCompress.scala:236-250): 2-byte form
+// iff len<=11 and offset<2048, else 3-byte form.  A long match is cut 64,64,...,(60),rest.
+__device__ __forceinline__ uint32_t emit_copy(uint8_t *__restrict__ out, uint32_t op, uint32_t offset,
+                                              uint32_t len, uint32_t lane)
+{
+    const uint32_t k64 = (len - 4) >> 6;  // number of leading 64-byte elements (len>=68 ? .. : 0)
+    uint32_t rest = len - (k64 << 6);     // 4..67
+    uint8_t *o = out + op;
+    const uint32_t lo = offset & 0xffu, hi = offset >> 8;
+    if (k64) {
+        const uint32_t w64 = 0xfeu | (lo << 8) | (hi << 16);  // 2 | (63<<2)
+        for (uint32_t j = lane; j < 3 * k64; j += 64)
+            o[j] = (uint8_t)(w64 >> (8 * (j % 3)));
+        o += 3 * k64;
+    }
+    uint32_t bytes = 3 * k64;
+    if (rest > 64) {
+        const uint32_t w60 = 0xeeu | (lo << 8) | (hi << 16);  // 2 | (59<<2)
+        if (lane < 3)
+            o[lane] = (uint8_t)(w60 >> (8 * lane));
+        o += 3;
+        bytes += 3;
+        rest -= 60;
+    }
+    uint32_t word, nb;
+    if (rest < 12 && offset < 2048) {
+        word = 1u | ((rest - 4) << 2) | ((offset >> 8) << 5) | (lo << 8);
+        nb = 2;
+    } else {
+        word = 2u | ((rest - 1) << 2) | (lo << 8) | (hi << 16);
+        nb = 3;
+    }
+    if (lane < nb)
+        o[lane] = (uint8_t)(word >> (8 * lane));
+    return op + bytes + nb;
+}
+
+// Match extension (a5): 4 + number of further equal bytes, compared up to the block end n.
+__device__ __forceinline__ uint32_t match_length(const uint8_t *__restrict__ in, uint32_t cand,
+                                                 uint32_t ip, uint32_t n, uint32_t lane)
+{
+    uint32_t m = 4;
+    {
+        const uint32_t i = m + lane;
+        const bool eq = (ip + i < n) && in[cand + i] == in[ip + i];
+        const uint64_t ne = ~__ballot(eq);
+        if (ne)
+            return m + ctz64(ne);
+        m += 64;
+    }
+    while (ip + m + 1024 <= n) {  // long match: 16 B per lane, 1 KiB per step
+        const u32x4 a = ld128(in + cand + m + 16 * lane);
+        const u32x4 b = ld128(in + ip + m + 16 * lane);
+        const uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
+        uint32_t eqb = 16;
+        if (d3) eqb = 12 + (__builtin_ctz(d3) >> 3);
+        if (d2) eqb = 8 + (__builtin_ctz(d2) >> 3);
+        if (d1) eqb = 4 + (__builtin_ctz(d1) >> 3);
+        if (d0) eqb = (__builtin_ctz(d0) >> 3);
+        const uint64_t ne = __ballot(eqb < 16);
+        if (ne) {
+            const uint32_t f = ctz64(ne);
+            return m + 16 * f + lane_get(eqb, f);
+        }
+        m += 1024;
+    }
+    for (;;) {
+        const uint32_t i = m + lane;
+        const bool eq = (ip + i < n) && in[cand + i] == in[ip + i];
+        const uint64_t ne = ~__ballot(eq);
+        if (ne)
+            return m + ctz64(ne);
+        m += 64;
+    }
+}
+
+// ------------------------------------------------------------------------ compress kernel
+
+__global__ __launch_bounds__(64) void compress_blocks_kernel(
+    const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
+    uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
+    uint32_t *__restrict__ out_len, uint32_t flags)
+{
+    // The whole LDS budget of this kernel: 32 KiB -> 5 workgroups per CU.
+    __shared__ __attribute__((aligned(16))) uint16_t table_mem[kMaxTable];
+    volatile uint16_t *tab = table_mem;  // volatile: LDS write->read-back must not be forwarded
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks)
+        return;
+    const uint8_t *__restrict__ in = src + (uint64_t)b * in_stride;
+    uint8_t *__restrict__ out = dst + (uint64_t)b * dst_stride;
+    // block length: explicit per block, or the fragments of one contiguous input (ragged tail), or fixed
+    uint32_t n_raw;
+    if (in_len)
+        n_raw = in_len[b];
+    else if (total_len) {
+        const uint64_t left = total_len - (uint64_t)b * in_stride;
+        n_raw = (uint32_t)(left < in_stride ? left : in_stride);
+    } else
+        n_raw = (uint32_t)in_stride;
+    const uint32_t n = uni(n_raw);
+    if (n > kMaxBlock) {  // caller error: flagged, nothing written
+        if (lane == 0)
+            out_len[b] = 0xffffffffu;
+        return;
+    }
+
+    uint32_t op = 0;
+    if (flags & kFlagBlockVarint) {  // (a8) varint32(n), n <= 65536 -> at most 3 bytes
+        const uint32_t nb = n < 128 ? 1 : (n < 16384 ? 2 : 3);
+        if (lane < nb)
+            out[lane] = (uint8_t)(((n >> (7 * lane)) & 0x7f) | (lane + 1 < nb ? 0x80 : 0));
+        op = nb;
+    }
+    if (n == 0) {
+        if (lane == 0)
+            out_len[b] = op;
+        return;
+    }
+
+    // (a2) zeroed uint16 table, T = clamp(pow2 >= n, 256, 16384)
+    uint32_t log2T = 8;
+    while (log2T < 14 && (1u << log2T) < n)
+        log2T++;
+    const uint32_t shift = 32 - log2T;
+    {
+        const uint32_t nvec = (1u << log2T) >> 3;  // 16-byte chunks
+        u32x4 z = {0, 0, 0, 0};
+        for (uint32_t i = lane; i < nvec; i += 64)
+            reinterpret_cast<u32x4 *>(table_mem)[i] = z;
+    }
+
+    uint32_t next_emit = 0;
+    if (n >= kInputMargin) {
+        const uint32_t ip_limit = n - kInputMargin;
+        uint32_t scan_base = 1;  // position of probe 0 of the current scan (skip == 32 there)
+        uint32_t n0 = 0;         // probes of this scan already done
+        for (;;) {
+            // ---------------- (a3) one speculative batch of up to 64 scan probes
+            const uint32_t idx = n0 + lane;
+            const uint32_t p = scan_base + g_probe.off[idx];
+            const uint32_t pn = scan_base + g_probe.off[idx + 1];
+            const bool valid = pn <= ip_limit;  // the reference checks next_ip before probing ip
+            uint32_t v = 0, h = 0, cand = 0, w = p & 0xffffu;
+            if (valid) {
+                v = ld32(in + p);
+                h = (v * kHashMul) >> shift;
+                cand = tab[h];
+                tab[h] = (uint16_t)p;
+                w = tab[h];
+            }
+            const uint32_t nvalid = (uint32_t)__builtin_popcountll(__ballot(valid));  // valid is a prefix
+            const uint64_t losers = __ballot(valid && w != (p & 0xffffu));
+            uint32_t cut = 64;
+            if (losers) {
+                // Two lanes of this batch share a bucket: serial order says the later one must see the
+                // earlier one's position.  Roll everything back, keep the longest collision-free prefix.
+                if (valid)
+                    tab[h] = (uint16_t)cand;
+                uint64_t L = losers;
+                while (L) {
+                    const uint32_t hv = lane_get(h, ctz64(L));
+                    const uint64_t G = __ballot(valid && h == hv);
+                    L &= ~G;
+                    const uint64_t G2 = G & (G - 1);
+                    const uint32_t second = ctz64(G2);
+                    cut = second < cut ? second : cut;
+                }
+                if (valid && lane < cut)
+                    tab[h] = (uint16_t)p;
+            }
+            const uint32_t nact = nvalid < cut ? nvalid : cut;
+            const bool act = lane < nact;
+            const uint32_t cv = act ? ld32(in + cand) : 0;
+            const uint64_t hits = __ballot(act && cv == v);
+            if (hits == 0) {
+                if (nact == nvalid && nvalid < 64)
+                    break;  // ran into ip_limit: remainder
+                n0 += nact;
+                continue;
+            }
+            const uint32_t f = ctz64(hits);
+            if (act && lane > f)
+                tab[h] = (uint16_t)cand;  // probes behind the first hit never happened
+            uint32_t ip = lane_get(p, f);
+            uint32_t cnd = lane_get(cand, f);
+
+            // ---------------- (a7) pending literal, then (a5)(a6) chain of copies
+            op = emit_literal(out, op, in + next_emit, ip - next_emit, lane);
+            bool more = true;
+            for (;;) {
+                const uint32_t m = match_length(in, cnd, ip, n, lane);
+                op = emit_copy(out, op, ip - cnd, m, lane);
+                ip += m;
+                next_emit = ip;
+                if (ip >= ip_limit) {
+                    more = false;
+                    break;
+                }
+                const uint64_t x = ld64(in + ip - 1);
+                const uint32_t vprev = (uint32_t)x, vcur = (uint32_t)(x >> 8);
+                tab[(vprev * kHashMul) >> shift] = (uint16_t)(ip - 1);
+                const uint32_t c = (vcur * kHashMul) >> shift;
+                cnd = tab[c];
+                tab[c] = (uint16_t)ip;
+                if (uni(ld32(in + cnd)) != uni(vcur))
+                    break;
+            }
+            if (!more)
+                break;
+            scan_base = ip + 1;  // (a4) miss after a copy: resume scanning one byte on, skip = 32
+            n0 = 0;
+        }
+    }
+    if (next_emit < n)
+        op = emit_literal(out, op, in + next_emit, n - next_emit, lane);
+    if (lane == 0)
+        out_len[b] = op;  // (a9)
+}
+
+// ---------------------------------------------------------------------- stream packing (8f-2)
+
+// Exclusive prefix sum of n lengths (+base) by one 1024-thread workgroup.
+__global__ __launch_bounds__(1024) void scan_lengths_kernel(const uint32_t *__restrict__ len, uint32_t n,
+                                                            uint64_t base, uint64_t *__restrict__ off)
+{
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = t * per < n ? t * per : n;
+    const uint32_t hi = lo + per < n ? lo + per : n;
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; i++)
+        s += len[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+        uint64_t add = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    uint64_t run = base + (t ? part[t - 1] : 0);
+    for (uint32_t i = lo; i < hi; i++) {
+        off[i] = run;
+        run += len[i];
+    }
+    if (t == 1023)
+        off[n] = base + part[1023];
+}
+
+__global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__restrict__ slots,
+                                                           uint64_t slot_stride,
+                                                           const uint32_t *__restrict__ len,
+                                                           const uint64_t *__restrict__ off,
+                                                           uint8_t *__restrict__ packed)
+{
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    const uint8_t *s = slots + (uint64_t)b * slot_stride;
+    uint8_t *d = packed + off[b];
+    uint32_t n = len[b];
+    uint32_t head = (16u - (uint32_t)((uintptr_t)d & 15u)) & 15u;
+    if (head > n)
+        head = n;
+    if (t < head)
+        d[t] = s[t];
+    d += head;
+    s += head;
+    n -= head;
+    const uint32_t nvec = n >> 4;
+    for (uint32_t i = t; i < nvec; i += 256)
+        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)i) = ld128(s + 16 * (size_t)i);
+    const uint32_t done = nvec << 4;
+    if (t < (n & 15u))
+        d[done + t] = s[done + t];
+}
+
+// -------------------------------------------------------------------- decompression (8f-1)
+
+// One wavefront per raw stream.  Elements are parsed serially (the format has no index); the
+// bytes of each element are moved by all 64 lanes.  Copies read back this wave's own earlier
+// stores to global memory: same wave, same address path, program order.
+__global__ __launch_bounds__(64) void uncompress_streams_kernel(
+    const uint8_t *__restrict__ src, uint64_t src_stride, const uint32_t *__restrict__ src_len,
+    uint32_t n_streams, uint8_t *dst, uint64_t dst_stride, uint32_t *__restrict__ out_len,
+    int32_t *__restrict__ status)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_streams)
+        return;
+    const uint8_t *__restrict__ in = src + (uint64_t)b * src_stride;
+    uint8_t *out = dst + (uint64_t)b * dst_stride;
+    const uint32_t n = uni(src_len[b]);
+    int32_t st = 0;
+    uint32_t ip = 0, op = 0, ulen = 0;
+
+    // preamble
+    {
+        uint32_t shiftv = 0;
+        bool ok = false;
+        for (uint32_t i = 0; i < 5 && i < n; i++) {
+            const uint32_t c = uni(in[i]);
+            if (i == 4 && c > 0x0f)
+                break;
+            ulen |= (c & 0x7f) << shiftv;
+            shiftv += 7;
+            if (c < 0x80) {
+                ok = true;
+                ip = i + 1;
+                break;
+            }
+        }
+        if (!ok)
+            st = kStatusCorrupt;
+        else if ((uint64_t)ulen > dst_stride)
+            st = kStatusNoSpace;
+    }
+
+    while (st == 0 && ip < n) {
+        // tag + up to 4 trailing bytes in one go when they are in bounds
+        uint32_t tag, extra = 0;
+        if (ip + 5 <= n) {
+            const uint64_t x = ld64(in + ip) ;
+            tag = uni((uint32_t)x & 0xff);
+            extra = uni((uint32_t)(x >> 8));
+        } else {
+            tag = uni(in[ip]);
+            for (uint32_t k = 1; k < 5 && ip + k < n; k++)
+                extra |= uni((uint32_t)in[ip + k]) << (8 * (k - 1));
+        }
+        const uint32_t kind = tag & 3;
+        if (kind == 0) {
+            uint32_t len = (tag >> 2) + 1, hdr = 1;
+            if (len > 60) {
+                const uint32_t nb = len - 60;
+                if (ip + 1 + nb > n) {
+                    st = kStatusCorrupt;
+                    break;
+                }
+                len = (nb == 4 ? extra : (extra & ((1u << (8 * nb)) - 1))) + 1;
+                hdr = 1 + nb;
+                if (len == 0) {  // 2^32 wrap
+                    st = kStatusCorrupt;
+                    break;
+                }
+            }
+            if ((uint64_t)ip + hdr + len > n || (uint64_t)op + len > ulen) {
+                st = kStatusCorrupt;
+                break;
+            }
+            wave_copy(out + op, in + ip + hdr, len, lane);
+            ip += hdr + len;
+            op += len;
+        } else {
+            uint32_t len, off, hdr;
+            if (kind == 1) {
+                hdr = 2;
+                len = ((tag >> 2) & 7) + 4;
+                off = ((tag >> 5) << 8) | (extra & 0xff);
+            } else if (kind == 2) {
+                hdr = 3;
+                len = (tag >> 2) + 1;
+                off = extra & 0xffff;
+            } else {
+                hdr = 5;
+                len = (tag >> 2) + 1;
+                off = extra;
+            }
+            if (ip + hdr > n || off == 0 || off > op || (uint64_t)op + len > ulen) {
+                st = kStatusCorrupt;
+                break;
+            }
+            // len <= 64: one byte per lane; an overlapping copy (off < len) repeats the last off
+            // bytes, so lane i reads byte (i mod off) of the window [op-off, op).
+            if (lane < len)
+                out[op + lane] = out[op - off + (lane % off)];
+            ip += hdr;
+            op += len;
+        }
+    }
+    if (st == 0 && op != ulen)
+        st = kStatusCorrupt;
+    if (lane == 0) {
+        out_len[b] = st == 0 ? op : 0;
+        status[b] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------ launchers
+
+hipError_t launch_compress_blocks(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len,
+                                  uint32_t n_blocks, void *d_dst, uint64_t dst_stride,
+                                  uint32_t *d_out_len, uint32_t flags, hipStream_t stream)
+{
+    if (n_blocks == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(compress_blocks_kernel, dim3(n_blocks), dim3(64), 0, stream,
+                       static_cast<const uint8_t *>(d_src), in_stride, d_in_len, (uint64_t)0, n_blocks,
+                       static_cast<uint8_t *>(d_dst), dst_stride, d_out_len, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_compress_stream(const void *d_src, uint64_t n, void *d_slots, uint64_t slot_stride,
+                                  uint32_t *d_len, uint32_t flags, hipStream_t stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    const uint32_t n_blocks = (uint32_t)((n + kMaxBlock - 1) / kMaxBlock);
+    hipLaunchKernelGGL(compress_blocks_kernel, dim3(n_blocks), dim3(64), 0, stream,
+                       static_cast<const uint8_t *>(d_src), (uint64_t)kMaxBlock,
+                       static_cast<const uint32_t *>(nullptr), n, n_blocks,
+                       static_cast<uint8_t *>(d_slots), slot_stride, d_len, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const uint32_t *d_len,
+                              uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
+                              hipStream_t stream)
+{
+    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, stream, d_len, n_blocks, base, d_off);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || n_blocks == 0)
+        return e;
+    hipLaunchKernelGGL(gather_slots_kernel, dim3(n_blocks), dim3(256), 0, stream,
+                       static_cast<const uint8_t *>(d_slots), slot_stride, d_len, d_off,
+                       static_cast<uint8_t *>(d_packed));
+    return hipGetLastError();
+}
+
+hipError_t launch_uncompress_streams(const void *d_src, uint64_t src_stride, const uint32_t *d_src_len,
+                                     uint32_t n_streams, void *d_dst, uint64_t dst_stride,
+                                     uint32_t *d_out_len, int32_t *d_status, hipStream_t stream)
+{
+    if (n_streams == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(uncompress_streams_kernel, dim3(n_streams), dim3(64), 0, stream,
+                       static_cast<const uint8_t *>(d_src), src_stride, d_src_len, n_streams,
+                       static_cast<uint8_t *>(d_dst), dst_stride, d_out_len, d_status);
+    return hipGetLastError();
+}
+
+}  // namespace szk

@@ -1,0 +1,133 @@
+/*
+ * include/snappy_hip.h -- C ABI of the MI355X-native Snappy block compressor.
+ *
+ * This is the drop-in boundary for the ONE hot path of nullromo/compression-accelerator:
+ *     compress(src, len, dst) -> compressed_len
+ * on independent <= 64 KiB blocks, byte-identical to software Snappy 1.1.8.
+ *
+ * Reference interfaces each entry point replaces (paths relative to the reference repo):
+ *
+ *   sz_rocc_cmd / rocc_cmd ........ the RoCC custom-3 command port:
+ *        funct 2 SET_LENGTH(rs1=len), funct 0 COMPRESS(rs1=src, rs2=dst) -> rd=compressed_len,
+ *        funct 1 UNCOMPRESS(rs1=src, rs2=dst) -> rd=0 on success
+ *        (tests/compression.c:8-15,20-39; src/main/scala/example/CompressionAccelerator.scala:54-73,
+ *         361-389,405-407; instruction encoders tests/rocc.h:30-46)
+ *   sz_compress / sz_uncompress ... snappy::Compress / snappy::Uncompress as called at
+ *        tests/swcompression.cc:27,31,45 and workloads/snappy/overlay/root/compress.cc:17
+ *        (C++ facade over these two: include/snappy/snappy.h)
+ *   sz_compress_blocks_hip ........ the accelerator datapath itself (match finder + hash table +
+ *        copy emitter + literal streamer: MatchFinder.scala:26-77, HashTable.scala:11-54,
+ *        CopyCompress.scala:44-190,211-273, CompressionAccelerator.scala:98-109,226-354) for a
+ *        batch of blocks already resident in HBM -- the form a multi-block caller
+ *        (workloads/snappy/overlay/root/run-all.sh style batch) binds.
+ *   sz_pack_stream_hip ............ turns per-block outputs into the single stream snappy::Compress
+ *        emits (one varint preamble + concatenated fragment bodies).
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer; 0 on success,
+ * negative SZ_E* on failure; no exceptions cross this boundary; no CPU fallback -- without a
+ * usable GPU every compute entry point returns SZ_ENODEV / SZ_EHIP.
+ * Device entry points are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ * default stream) and are graph-capture safe (no allocation, no synchronisation inside).
+ */
+#ifndef SNAPPY_HIP_H
+#define SNAPPY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SZ_BLOCK_SIZE 65536u      /* Snappy fragment size: one block per wavefront */
+#define SZ_SLOT_STRIDE 76544u     /* default output slot: >= sz_max_compressed_length(65536)=76490, 128-B multiple */
+
+#define SZ_OK 0
+#define SZ_EINVAL (-22)
+#define SZ_ENOSPC (-28)
+#define SZ_EHIP (-5)              /* a HIP runtime call failed; see sz_last_hip_error() */
+#define SZ_ENODEV (-19)           /* no usable GPU */
+#define SZ_ECORRUPT (-74)         /* malformed compressed stream (EBADMSG) */
+
+/* flags of sz_compress_blocks_hip */
+#define SZ_FLAG_BLOCK_VARINT 1u   /* prepend varint32(in_len) to every block: each slot is a
+                                     self-contained Snappy raw stream (== snappy::RawCompress of
+                                     that block).  Without it slots hold fragment bodies only. */
+
+/* RoCC command surface constants (tests/compression.c:8-15) */
+#define SZ_ROCC_CHANNEL 3
+#define SZ_ROCC_COMPRESS 0
+#define SZ_ROCC_UNCOMPRESS 1
+#define SZ_ROCC_SET_LENGTH 2
+
+/* ---- sizing ---------------------------------------------------------------------------- */
+
+/* 32 + n + n/6, identical to snappy::MaxCompressedLength. */
+size_t sz_max_compressed_length(size_t n);
+
+/* ---- device-resident batch API (the hot path) --------------------------------------------
+ * Block b reads d_src + b*in_stride, d_in_len[b] bytes (d_in_len == NULL: in_stride bytes each;
+ * every length must be <= 65536), and writes d_dst + b*dst_stride and d_out_len[b].
+ * dst_stride must be >= sz_max_compressed_length(longest block) + 5.
+ * One 64-lane wavefront per block, hash table in LDS. */
+int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *d_in_len,
+                           uint32_t n_blocks, void *d_dst, size_t dst_stride,
+                           uint32_t *d_out_len, uint32_t flags, void *stream);
+
+/* Same kernel for ONE contiguous input of n bytes (n < 2^32) cut into consecutive 64 KiB fragments
+ * (the last one ragged): fragment k goes to d_slots + k*slot_stride, its length to d_len[k].
+ * Number of fragments = ceil(n / 65536).  This is the fragment loop of snappy::Compress. */
+int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t slot_stride,
+                           uint32_t *d_len, uint32_t flags, void *stream);
+
+/* Exclusive prefix sum of d_len[0..n_blocks) + base into d_off[0..n_blocks], d_off[n_blocks] =
+ * total; then gathers slot b (d_slots + b*slot_stride, d_len[b] bytes) to d_packed + d_off[b].
+ * With base = size of the stream's varint preamble this yields the body of snappy::Compress.
+ * d_off must hold n_blocks+1 uint64. */
+int sz_pack_stream_hip(const void *d_slots, size_t slot_stride, const uint32_t *d_len,
+                       uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
+                       void *stream);
+
+/* Batch decompression: stream b is d_src + b*src_stride, d_src_len[b] bytes (a raw Snappy
+ * stream with preamble); decoded bytes go to d_dst + b*dst_stride (capacity dst_stride),
+ * d_out_len[b] receives the decoded size, d_status[b] 0 or SZ_ECORRUPT/SZ_ENOSPC. */
+int sz_uncompress_blocks_hip(const void *d_src, size_t src_stride, const uint32_t *d_src_len,
+                             uint32_t n_streams, void *d_dst, size_t dst_stride,
+                             uint32_t *d_out_len, int32_t *d_status, void *stream);
+
+/* ---- host-buffer convenience API (what the snappy:: facade and the RoCC surface call) ---- */
+
+/* Exactly the bytes of snappy::Compress(src, n): varint32(n) + bodies of consecutive 64 KiB
+ * fragments, all fragments compressed on the GPU in one launch.  n < 2^32. */
+int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len);
+
+/* snappy::Uncompress on the GPU.  *out_len receives the decoded size. */
+int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len);
+
+/* snappy::GetUncompressedLength (host-side varint parse, no GPU needed). */
+int sz_get_uncompressed_length(const void *src, size_t n, size_t *result);
+
+/* ---- RoCC command surface ----------------------------------------------------------------
+ * Per-thread accelerator state (the latched length), one outstanding command, blocking, as
+ * CompressionAccelerator.scala:72 (cmd.ready := !busy).  COMPRESS writes the full Snappy raw
+ * stream (preamble + elements) so that UNCOMPRESS and any software Snappy can read it back.
+ * Returns 0 and sets *rd, or a negative SZ_E* (bad channel/funct, no GPU). */
+int sz_rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2, uint64_t *rd);
+
+/* Same, shaped for the instruction macros (include/rocc_host_shim.h): returns rd; on error
+ * returns (uint64_t)-1 and records the code for sz_rocc_last_error(). */
+uint64_t rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2);
+int sz_rocc_last_error(void);
+
+/* ---- misc ------------------------------------------------------------------------------- */
+/* Frees the calling thread's cached device workspace (used by the host-buffer API). */
+void sz_release_thread_resources(void);
+int sz_device_count(void);            /* number of visible GPUs (0 if none / no driver) */
+int sz_last_hip_error(void);          /* last hipError_t seen by this thread */
+const char *sz_strerror(int code);
+const char *sz_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNAPPY_HIP_H */

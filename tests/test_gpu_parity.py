@@ -1,0 +1,123 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the oracle on the same seeded inputs and against the committed goldens (bit-exact)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fuzzgen
+import oracle_lib
+from gpu_util import compress_many, pkg
+
+pytestmark = pytest.mark.gpu
+
+G = fuzzgen.GOLDEN_DIR
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def _first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return i
+    return n
+
+
+def _assert_same(got, want, what):
+    assert got == want, "%s: GPU %d bytes vs oracle %d bytes, first difference at %d" % (
+        what, len(got), len(want), _first_diff(got, want))
+
+
+def test_native_library_is_loaded_and_sees_the_gpu():
+    P = pkg()
+    assert P.device_count() >= 1
+    assert os.path.exists(P.LIB_PATH)
+    with open("/proc/self/maps") as f:
+        assert "libsnappy_hip.so" in f.read()
+
+
+def test_edge_sizes_all_kinds():
+    sizes = [0, 1, 2, 3, 4, 5, 13, 14, 15, 16, 17, 18, 19, 20, 31, 32, 33, 59, 60, 61, 62, 63, 64, 65, 66, 67,
+             68, 69, 127, 128, 129, 255, 256, 257, 258, 1000, 2047, 2048, 2049, 4096, 5000, 16383, 16384,
+             16385, 65521, 65535, 65536]
+    blocks, names = [], []
+    seed = 9000
+    for kind in fuzzgen.KINDS:
+        for n in sizes:
+            blocks.append(fuzzgen.gen(kind, seed, n).tobytes())
+            names.append((kind, seed, n))
+            seed += 1
+    got = compress_many(blocks)
+    for g, b, nm in zip(got, blocks, names):
+        _assert_same(g, oracle_lib.raw_compress(b), str(nm))
+
+
+def test_body_only_mode_has_no_preamble():
+    blocks = [fuzzgen.gen(k, 7 + i, n).tobytes() for i, (k, n) in enumerate(
+        [("text_mtg", 65536), ("random", 100), ("lz", 30000), ("same", 65536), ("words", 0)])]
+    got = compress_many(blocks, varint=False)
+    for g, b in zip(got, blocks):
+        _assert_same(g, oracle_lib.compress_fragment(b), "body-only %d" % len(b))
+
+
+def test_fuzz_goldens_from_libsnappy_1_1_8():
+    with open(os.path.join(G, "golden_fuzz.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["n"] <= 65536]
+    blocks = [fuzzgen.gen(c["kind"], c["seed"], c["n"]).tobytes() for c in cases]
+    got = compress_many(blocks)
+    bad = [(c["kind"], c["seed"], c["n"]) for c, g in zip(cases, got)
+           if len(g) != c["out_len"] or sha(g) != c["out_sha256"]]
+    assert not bad, bad[:10]
+
+
+def test_file_goldens_per_block():
+    with open(os.path.join(G, "golden_files.json")) as f:
+        files = json.load(f)["files"]
+    import test_oracle
+    for e in files:
+        data = test_oracle._input_for(e["name"])
+        blocks = [data[o:o + 65536] for o in range(0, len(data), 65536)] or [b""]
+        got = compress_many(blocks)
+        if "blocks" in e:
+            for k, (g, gb) in enumerate(zip(got, e["blocks"])):
+                assert (len(g), sha(g)) == (gb["out_len"], gb["out_sha256"]), "%s block %d" % (e["name"], k)
+        if len(blocks) == 1:
+            assert (len(got[0]), sha(got[0])) == (e["out_len"], e["out_sha256"]), e["name"]
+            if "out_hex" in e:
+                assert got[0].hex() == e["out_hex"]
+
+
+def test_random_differential_vs_oracle():
+    rs = np.random.RandomState(4242)
+    blocks = []
+    for i in range(1500):
+        kind = fuzzgen.KINDS[int(rs.randint(0, len(fuzzgen.KINDS)))]
+        n = int(rs.randint(0, 3000)) if i % 4 else int(rs.randint(0, 65537))
+        blocks.append(fuzzgen.gen(kind, 500000 + i, n).tobytes())
+    got = compress_many(blocks)
+    for i, (g, b) in enumerate(zip(got, blocks)):
+        _assert_same(g, oracle_lib.raw_compress(b), "case %d" % i)
+
+
+def test_bucket_collision_stress():
+    """Inputs engineered so that many probes of one speculative batch share a hash bucket
+    (the intra-batch ordering path of the kernel): few distinct 4-byte shingles, short periods."""
+    rs = np.random.RandomState(99)
+    blocks = []
+    for period in (1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129):
+        pat = rs.randint(0, 256, size=period).astype(np.uint8)
+        for n in (200, 4096, 65536):
+            a = np.resize(pat, n).copy()
+            blocks.append(a.tobytes())
+            # same thing with sparse random corruptions so matches keep breaking
+            k = max(1, n // 97)
+            a[rs.randint(0, n, size=k)] ^= rs.randint(1, 256, size=k).astype(np.uint8)
+            blocks.append(a.tobytes())
+    got = compress_many(blocks)
+    for i, (g, b) in enumerate(zip(got, blocks)):
+        _assert_same(g, oracle_lib.raw_compress(b), "collision case %d (n=%d)" % (i, len(b)))
