@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- Snappy block compression throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|text|c5|mix] [--blocks-per-gpu B]
+
+A "step" is one pass of the hot path (sz_compress_blocks_hip through the C ABI) over this rank's
+blocks, input already resident in HBM, plus -- for N>1 -- the RCCL all_gather of the per-block
+lengths.  Prints ONE JSON line on rank 0.  N>1 is launched by torch.distributed.run (one process
+per GPU); blocks shard by contiguous ranges, weak scaling (fixed blocks per GPU).
+
+Headline workload (config.workload): C3 = consecutive 64 KiB windows of the infinite tiling of
+data/randomASCII.txt (BASELINE.json configs[2], the one the north-star target is quoted on);
+--blocks-per-gpu 32768 (2 GiB per GPU) so that N=8 is config C4's 16 GiB.  Short passes over the
+text (C2-like), low-entropy (C5) and mixed (C4 mix) workloads are reported in "workloads".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BLOCK = 65536
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def make_input(kind, first_block, n_blocks, device):
+    """Builds this rank's blocks [first_block, first_block+n_blocks) directly in HBM."""
+    import torch
+    import fuzzgen
+
+    def tiling(src_bytes, start, total):
+        src = torch.from_numpy(np.frombuffer(src_bytes, dtype=np.uint8).copy()).to(device)
+        L = src.numel()
+        start %= L
+        reps = (start + total + L - 1) // L
+        return src.repeat(reps)[start:start + total].contiguous()
+
+    total = n_blocks * BLOCK
+    if kind == "c3":
+        return tiling(fuzzgen.corpus("random_ascii"), first_block * BLOCK, total)
+    if kind == "text":
+        return tiling(fuzzgen.corpus("mtg"), first_block * BLOCK, total)
+    if kind == "c5":
+        mtg = torch.from_numpy(np.frombuffer(fuzzgen.corpus("mtg"), dtype=np.uint8).copy()).to(device)
+        span = mtg.numel() - 4096
+        k = torch.arange(first_block, first_block + n_blocks, device=device, dtype=torch.int64)
+        starts = (k * 4099) % span
+        idx = starts[:, None] + torch.arange(4096, device=device, dtype=torch.int64)[None, :]
+        pats = mtg[idx]  # [n_blocks, 4096]
+        return pats.repeat(1, 16).reshape(-1).contiguous()
+    if kind == "mix":  # config C4's recommended mix: block k -> k%3 in {c3, text, c5}
+        parts = [make_input(w, first_block, n_blocks, device).reshape(n_blocks, BLOCK) for w in ("c3", "text", "c5")]
+        sel = (torch.arange(first_block, first_block + n_blocks, device=device) % 3)
+        out = parts[0].clone()
+        for j in (1, 2):
+            out[sel == j] = parts[j][sel == j]
+        return out.reshape(-1).contiguous()
+    raise KeyError(kind)
+
+
+def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on, verify_blocks=8):
+    """Returns dict with timing of `steps` steps (max over ranks), kernel-only event times, sizes."""
+    import torch
+    import torch.distributed as dist
+    import oracle_lib
+    from compression_accelerator_amd import sharding as shard
+
+    src = make_input(kind, first_block, n_blocks, device)
+    dst = torch.empty(n_blocks * P.SLOT_STRIDE, dtype=torch.uint8, device=device)
+    out_len = torch.zeros(n_blocks, dtype=torch.int32, device=device)
+    world = dist.get_world_size() if dist_on else 1
+
+    def step():
+        P.compress_blocks(src, BLOCK, n_blocks, dst=dst, out_len=out_len, varint=True)
+        if dist_on:
+            shard.gather_lengths(out_len, n_blocks * world)
+
+    for _ in range(warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()  # same stream as the kernel launch (torch's current stream)
+        P.compress_blocks(src, BLOCK, n_blocks, dst=dst, out_len=out_len, varint=True)
+        ev[i][1].record()
+        if dist_on:
+            shard.gather_lengths(out_len, n_blocks * world)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+
+    # ---- checks, outside the timed region: sample blocks against the oracle, all lengths sane
+    lens = out_len.cpu().numpy().astype(np.int64)
+    out_bytes = int(lens.sum())
+    pick = np.unique(np.linspace(0, n_blocks - 1, verify_blocks).astype(np.int64))
+    host_in = src.reshape(n_blocks, BLOCK)[torch.from_numpy(pick).to(device)].cpu().numpy()
+    host_out = dst.reshape(n_blocks, P.SLOT_STRIDE)[torch.from_numpy(pick).to(device)].cpu().numpy()
+    exact = True
+    for j, b in enumerate(pick):
+        want = oracle_lib.raw_compress(host_in[j])
+        exact &= host_out[j, :lens[b]].tobytes() == want
+    del src, dst
+    return {"elapsed_s": elapsed, "kernel_ms": kernel_ms, "in_bytes": n_blocks * BLOCK, "out_bytes": out_bytes,
+            "bit_exact_sample": bool(exact), "n_blocks": n_blocks}
+
+
+def cpu_baseline(kind, sample_blocks, budget_s=12.0):
+    """The oracle (kind "port": bit-exact CPU restatement of Snappy 1.1.8) on the host cores,
+    bounded sample of the same workload."""
+    import torch
+    import oracle_lib
+    src = make_input(kind, 0, sample_blocks, "cpu").numpy()
+    cores = min(len(os.sched_getaffinity(0)), 16)  # the box's CPU share for one GPU
+    res = {}
+    for threads in (1, cores):
+        n_pass, t_used = 0, 0.0
+        while t_used < budget_s / 2 and n_pass < 50:
+            t0 = time.perf_counter()
+            oracle_lib.compress_blocks(src, BLOCK, sample_blocks, per_block_varint=True, threads=threads)
+            t_used += time.perf_counter() - t0
+            n_pass += 1
+        res[threads] = sample_blocks * BLOCK * n_pass / t_used / 1e9
+    return {"value": round(res[cores], 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "single_thread_GBps": round(res[1], 3),
+            "sample": "%d x 64 KiB blocks of workload %s, oracle/snappy_oracle.c, %d pthreads" % (sample_blocks, kind, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c3", "text", "c5", "mix"])
+    ap.add_argument("--blocks-per-gpu", type=int, default=32768)
+    ap.add_argument("--no-extra", action="store_true", help="skip the short text/c5/mix passes")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pkg_loader import load_package
+    P = load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist_on = world > 1
+    if dist_on:
+        dist.init_process_group("nccl", device_id=device)
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    B = args.blocks_per_gpu
+    first = rank * B
+    main_res = run_workload(P, args.workload, first, B, args.steps, args.warmup, device, dist_on)
+
+    extras = {}
+    if not args.no_extra:
+        for kind, nb in (("text", 4096), ("c5", 8192), ("mix", 6144)):
+            if kind == args.workload:
+                continue
+            r = run_workload(P, kind, rank * nb, nb, 3, 1, device, dist_on)
+            k_ms = float(np.mean(r["kernel_ms"]))
+            extras[kind] = {"input_GBps": round(r["in_bytes"] * world * 3 / r["elapsed_s"] / 1e9, 2),
+                            "kernel_ms": round(k_ms, 3), "blocks_per_gpu": nb,
+                            "compression_ratio": round(r["in_bytes"] / r["out_bytes"], 4),
+                            "hbm_frac_in_plus_out": round((r["in_bytes"] + r["out_bytes"]) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "bit_exact_sample": r["bit_exact_sample"]}
+
+    exact_all = main_res["bit_exact_sample"]
+    if dist_on:
+        t = torch.tensor([1 if exact_all else 0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        exact_all = bool(t.item())
+
+    if rank == 0:
+        K = args.steps
+        total_in = main_res["in_bytes"] * world
+        value = total_in * K / main_res["elapsed_s"] / 1e9
+        k_ms = float(np.mean(main_res["kernel_ms"]))
+        algo_bytes = main_res["in_bytes"] + main_res["out_bytes"] + 4 * B  # per launch (this rank)
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "snappy_compress_input_GBps_64KiB_blocks",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(main_res["elapsed_s"] / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": {"c3": "C3 tiled data/randomASCII.txt", "text": "C2-like tiled all-mtg-cards.txt",
+                                    "c5": "C5 4 KiB text pattern x16", "mix": "C4 mix c3/text/c5"}[args.workload]
+                       + ", %d x 64 KiB blocks per GPU (%.2f GiB/GPU)" % (B, B * BLOCK / 2**30),
+                       "blocks_per_gpu": B, "block_bytes": BLOCK,
+                       "sharding": "contiguous block ranges, no data-path collective; all_gather of uint32 lengths over RCCL"},
+            "compressed_size_ratio_vs_ref": 1.0 if exact_all else None,
+            "bit_exact_vs_oracle_sample": exact_all,
+            "compression_ratio": round(main_res["in_bytes"] / main_res["out_bytes"], 5),
+            "input_frac_of_hbm_peak": round(main_res["in_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "szk::compress_blocks_kernel", "kernel_ms_avg": round(k_ms, 4),
+                         "algorithmic_bytes_per_launch": algo_bytes},
+            "workloads": extras,
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(args.workload, 1024)
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

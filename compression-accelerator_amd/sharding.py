@@ -1,0 +1,42 @@
+"""Multi-GPU sharding of the block-compression path.
+
+Every <=64 KiB block is independent (fresh hash table per fragment), so the path shards by
+contiguous block ranges with NO data-path collective.  The only exchange is the final gather of
+per-block compressed lengths (uint32 per block) so that every rank knows the global layout of the
+packed stream: one all_gather over RCCL/xGMI (backend "nccl" on ROCm), or gloo on CPU in tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_blocks_total, rank, world):
+    """Contiguous, balanced block range [begin, end) of `rank` (first ranks get the remainder)."""
+    base, rem = divmod(n_blocks_total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def gather_lengths(local_lens, n_blocks_total=None, group=None):
+    """all_gather of per-block lengths.  local_lens: int32 tensor [blocks of this rank] (CUDA for
+    nccl, CPU for gloo).  Returns (all_lens int32[n_total], offsets int64[n_total+1]) where
+    offsets is the exclusive prefix sum = position of every block in the packed global stream.
+    Ranks may hold different block counts (shard_range); shorter ones are padded for the collective."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        all_lens = local_lens
+    else:
+        world = dist.get_world_size(group)
+        if n_blocks_total is None:
+            n_blocks_total = int(local_lens.numel()) * world
+        per = -(-n_blocks_total // world)
+        pad = torch.zeros(per, dtype=local_lens.dtype, device=local_lens.device)
+        pad[:local_lens.numel()] = local_lens
+        out = torch.empty(per * world, dtype=local_lens.dtype, device=local_lens.device)
+        dist.all_gather_into_tensor(out, pad, group=group)
+        pieces = []
+        for r in range(world):
+            b, e = shard_range(n_blocks_total, r, world)
+            pieces.append(out[r * per:r * per + (e - b)])
+        all_lens = torch.cat(pieces)
+    offsets = torch.zeros(all_lens.numel() + 1, dtype=torch.int64, device=all_lens.device)
+    torch.cumsum(all_lens.to(torch.int64), dim=0, out=offsets[1:])
+    return all_lens, offsets

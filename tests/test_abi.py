@@ -1,0 +1,100 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/snappy_hip.h declares, the reference-shaped drivers build against include/, and -- on a
+machine without a GPU -- the product path fails loudly instead of falling back to a CPU path."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import build_util
+from pkg_loader import load_package
+
+ROOT = build_util.ROOT
+REF = "/root/reference"
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "snappy_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:sz_|rocc_)[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    P = load_package()
+    L = ctypes.CDLL(P.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 16
+    for s in declared:
+        assert hasattr(L, s), "libsnappy_hip.so does not export %s" % s
+    assert set(declared) == set(P.ABI_SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", P.LIB_PATH]).decode()
+    exported = set(re.findall(r" T ((?:sz_|rocc_)\w+)", out))
+    assert exported == set(declared), exported ^ set(declared)
+
+
+def test_no_torch_or_oracle_in_the_abi_library():
+    P = load_package()
+    out = subprocess.check_output(["readelf", "-d", P.LIB_PATH]).decode()
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert any("amdhip64" in n for n in needed)
+    assert not any(("torch" in n) or ("c10" in n) or ("oracle" in n) or ("snappy.so" in n) for n in needed), needed
+    # the product sources never mention the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "compression-accelerator_amd")):
+        for f in files:
+            if f.endswith((".hip", ".cpp", ".h", ".c", ".cc", ".py")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle_" not in txt and "liboracle" not in txt, f
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        p = os.path.join(ROOT, "include", f)
+        if os.path.isfile(p):
+            assert "oracle_" not in open(p).read()
+
+
+def test_sizing_and_varint_helpers_need_no_gpu():
+    P = load_package()
+    for n in (0, 1, 100, 65536, 10**6):
+        assert P.max_compressed_length(n) == 32 + n + n // 6
+    assert P.max_compressed_length(65536) == 76490 <= P.SLOT_STRIDE
+    assert P.uncompressed_length(bytes([0x82, 0x01, 0xb0])) == 130
+    assert P.uncompressed_length(bytes([0x80, 0x80, 0x04])) == 65536
+    with pytest.raises(P.SnappyHipError):
+        P.uncompressed_length(b"\xff\xff\xff\xff\xff")
+    assert P.lib().sz_strerror(P.SZ_ENODEV) == b"no usable GPU"
+    assert b"gfx950" in P.lib().sz_version()
+
+
+def test_rocc_surface_argument_checks():
+    P = load_package()
+    rd = ctypes.c_uint64(7)
+    L = P.lib()
+    assert L.sz_rocc_cmd(2, P.ROCC_SET_LENGTH, 10, 0, ctypes.byref(rd)) == P.SZ_EINVAL  # wrong channel
+    assert L.sz_rocc_cmd(3, 9, 0, 0, ctypes.byref(rd)) == P.SZ_EINVAL  # unknown funct
+    assert L.sz_rocc_cmd(3, P.ROCC_SET_LENGTH, 130, 0, ctypes.byref(rd)) == P.SZ_OK and rd.value == 0
+
+
+def test_fails_loudly_without_a_gpu(tmp_path):
+    P = load_package()
+    if P.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(P.SnappyHipError) as e:
+        P.compress(b"hello hello hello hello")
+    assert e.value.code == P.SZ_ENODEV
+    exe = build_util.cc(os.path.join(build_util.DRIVERS, "rocc_compress.c"), str(tmp_path / "rocc_compress"))
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 3 and b"no usable GPU" in r.stderr
+
+
+def test_own_drivers_build(tmp_path):
+    build_util.cc(os.path.join(build_util.DRIVERS, "rocc_compress.c"), str(tmp_path / "a"))
+    build_util.cxx(os.path.join(build_util.DRIVERS, "sw_benchmark.cc"), str(tmp_path / "b"))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+def test_reference_drivers_build_unchanged(tmp_path):
+    """tests/compression.c, tests/swcompression.cc and the FireSim workload's compress.cc compile
+    and link UNCHANGED against include/ + libsnappy_hip.so."""
+    build_util.cc(os.path.join(REF, "tests", "compression.c"), str(tmp_path / "c1"), force_shim=True)
+    build_util.cxx(os.path.join(REF, "tests", "swcompression.cc"), str(tmp_path / "c2"))
+    build_util.cxx(os.path.join(REF, "workloads", "snappy", "overlay", "root", "compress.cc"), str(tmp_path / "c3"))

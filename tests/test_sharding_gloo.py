@@ -1,0 +1,83 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU path: block-range sharding + the one collective
+(all_gather of per-block lengths).  Per-rank lengths come from the oracle here; on GPUs they come
+from the kernel, the exchange code is the same (compression-accelerator_amd/sharding.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import fuzzgen
+import oracle_lib
+from pkg_loader import load_package
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _blocks(n_total):
+    data = fuzzgen.corpus("mtg")
+    return [data[k * 65536:(k + 1) * 65536] for k in range(n_total)]
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    load_package()
+    from compression_accelerator_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = sharding.shard_range(n_total, rank, world)
+    lens = torch.tensor([len(oracle_lib.raw_compress(x)) for x in _blocks(n_total)[b:e]], dtype=torch.int32)
+    all_lens, offs = sharding.gather_lengths(lens, n_total)
+    q.put((rank, all_lens.numpy().tolist(), offs.numpy().tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 7])
+def test_two_rank_length_gather_matches_single_process(n_total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [len(oracle_lib.raw_compress(x)) for x in _blocks(n_total)]
+    want_off = np.concatenate([[0], np.cumsum(want)]).tolist()
+    for rank, lens, offs in res:
+        assert lens == want, rank
+        assert offs == want_off, rank
+
+
+def test_shard_range_partitions_exactly():
+    load_package()
+    from compression_accelerator_amd import sharding
+    for n in (0, 1, 7, 8, 48, 262144, 262147):
+        for world in (1, 2, 3, 4, 8):
+            r = [sharding.shard_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [e - b for b, e in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_gather_is_identity():
+    load_package()
+    from compression_accelerator_amd import sharding
+    lens = torch.tensor([5, 7, 11], dtype=torch.int32)
+    a, o = sharding.gather_lengths(lens)
+    assert a.tolist() == [5, 7, 11] and o.tolist() == [0, 5, 12, 23]
