@@ -35,7 +35,7 @@ static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:7
 // Probe schedule of the scan loop after a (re)start: off[k] = distance of the k-th probe from the
 // first one.  skip_0 = 32, off_{k+1} = off_k + (skip_k >> 5), skip_{k+1} = skip_k + (skip_k >> 5).
 // 266 probes span 64 KiB; entries past that saturate so they always fail the limit check.
-static constexpr int kProbeEntries = 384;
+static constexpr int kProbeEntries = 448;
 struct ProbeSchedule {
     uint32_t off[kProbeEntries];
 };
@@ -59,6 +59,8 @@ __device__ const ProbeSchedule g_probe = make_probe_schedule();
 
 // ------------------------------------------------------------------------------- helpers
 
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p)
 {
     uint32_t v;
@@ -77,6 +79,10 @@ __device__ __forceinline__ u32x4 ld128(const uint8_t *p)
     __builtin_memcpy(&v, p, 16);
     return v;
 }
+__device__ __forceinline__ u32x4 ld128_nt(const uint8_t *p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
+}
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l)
 {
@@ -84,7 +90,32 @@ __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l)
 }
 __device__ __forceinline__ uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 
-// Cooperative byte copy by one wave, dst-aligned 16-byte stores in the bulk.
+// dword at byte offset `off` of a block of n bytes; bytes past the end read as 0 (never touched)
+__device__ __forceinline__ uint32_t ld32_clamped(const uint8_t *in, uint32_t off, uint32_t n)
+{
+    if (off + 4 <= n)
+        return ld32(in + off);
+    uint32_t v = 0;
+    if (off < n) v |= in[off];
+    if (off + 1 < n) v |= (uint32_t)in[off + 1] << 8;
+    if (off + 2 < n) v |= (uint32_t)in[off + 2] << 16;
+    return v;
+}
+
+// Number of leading equal bytes (4..16) of two 16-byte strings whose first 4 bytes are equal.
+__device__ __forceinline__ uint32_t matchlen16(uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b1,
+                                               uint32_t b2, uint32_t b3)
+{
+    const uint32_t d1 = a1 ^ b1, d2 = a2 ^ b2, d3 = a3 ^ b3;
+    uint32_t m = 16;
+    if (d3) m = 12 + (__builtin_ctz(d3) >> 3);
+    if (d2) m = 8 + (__builtin_ctz(d2) >> 3);
+    if (d1) m = 4 + (__builtin_ctz(d1) >> 3);
+    return m;
+}
+
+// Cooperative byte copy by one wave, dst-aligned 16-byte stores in the bulk; long copies stream
+// with non-temporal loads/stores, 8 KiB in flight.
 __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s,
                                           uint32_t len, uint32_t lane)
 {
@@ -101,7 +132,17 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t
     len -= head;
     const uint32_t nvec = len >> 4;
     uint32_t i = lane;
-    // 4 x 1 KiB in flight per step
+    if (nvec >= 512) {
+        for (; i + 448 < nvec; i += 512) {
+            u32x4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                q[u] = ld128_nt(s + 16 * (size_t)(i + 64 * u));
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                __builtin_nontemporal_store(q[u], reinterpret_cast<u32x4 *>(d + 16 * (size_t)(i + 64 * u)));
+        }
+    }
     for (; i + 192 < nvec; i += 256) {
         u32x4 q0 = ld128(s + 16 * (size_t)i);
         u32x4 q1 = ld128(s + 16 * (size_t)(i + 64));
@@ -148,24 +189,26 @@ __device__ __forceinline__ uint32_t emit_literal(uint8_t *__restrict__ out, uint
 __device__ __forceinline__ uint32_t emit_copy(uint8_t *__restrict__ out, uint32_t op, uint32_t offset,
                                               uint32_t len, uint32_t lane)
 {
-    const uint32_t k64 = (len - 4) >> 6;  // number of leading 64-byte elements (len>=68 ? .. : 0)
-    uint32_t rest = len - (k64 << 6);     // 4..67
-    uint8_t *o = out + op;
     const uint32_t lo = offset & 0xffu, hi = offset >> 8;
-    if (k64) {
+    uint8_t *o = out + op;
+    uint32_t bytes = 0;
+    uint32_t rest = len;
+    if (len > 64) {
+        const uint32_t k64 = (len - 4) >> 6;  // number of leading 64-byte elements
+        rest = len - (k64 << 6);              // 4..67
         const uint32_t w64 = 0xfeu | (lo << 8) | (hi << 16);  // 2 | (63<<2)
         for (uint32_t j = lane; j < 3 * k64; j += 64)
             o[j] = (uint8_t)(w64 >> (8 * (j % 3)));
         o += 3 * k64;
-    }
-    uint32_t bytes = 3 * k64;
-    if (rest > 64) {
-        const uint32_t w60 = 0xeeu | (lo << 8) | (hi << 16);  // 2 | (59<<2)
-        if (lane < 3)
-            o[lane] = (uint8_t)(w60 >> (8 * lane));
-        o += 3;
-        bytes += 3;
-        rest -= 60;
+        bytes = 3 * k64;
+        if (rest > 64) {
+            const uint32_t w60 = 0xeeu | (lo << 8) | (hi << 16);  // 2 | (59<<2)
+            if (lane < 3)
+                o[lane] = (uint8_t)(w60 >> (8 * lane));
+            o += 3;
+            bytes += 3;
+            rest -= 60;
+        }
     }
     uint32_t word, nb;
     if (rest < 12 && offset < 2048) {
@@ -180,11 +223,10 @@ __device__ __forceinline__ uint32_t emit_copy(uint8_t *__restrict__ out, uint32_
     return op + bytes + nb;
 }
 
-// Match extension (a5): 4 + number of further equal bytes, compared up to the block end n.
+// Match extension (a5): `m` bytes are already known equal; compares on up to the block end n.
 __device__ __forceinline__ uint32_t match_length(const uint8_t *__restrict__ in, uint32_t cand,
-                                                 uint32_t ip, uint32_t n, uint32_t lane)
+                                                 uint32_t ip, uint32_t n, uint32_t lane, uint32_t m)
 {
-    uint32_t m = 4;
     {
         const uint32_t i = m + lane;
         const bool eq = (ip + i < n) && in[cand + i] == in[ip + i];
@@ -219,6 +261,89 @@ __device__ __forceinline__ uint32_t match_length(const uint8_t *__restrict__ in,
     }
 }
 
+// 1 KiB sliding window of the input STREAM side held in registers: lane l keeps the dwords at
+// base + 256*j + 4*l in wj (j = 0..3), base a multiple of 256.  The copy chain reads the bytes at
+// ip-1 .. ip+16 from here with v_readlane instead of a dependent global load; the refill load is
+// issued >= 512 bytes ahead of use.  (Four separate scalars, not a struct/array: see sel6.)
+__device__ __forceinline__ void win_load_all(const uint8_t *__restrict__ in, uint32_t n, uint32_t lane,
+                                             uint32_t base, uint32_t &w0, uint32_t &w1, uint32_t &w2,
+                                             uint32_t &w3)
+{
+    w0 = ld32_clamped(in, base + 4 * lane, n);
+    w1 = ld32_clamped(in, base + 256 + 4 * lane, n);
+    w2 = ld32_clamped(in, base + 512 + 4 * lane, n);
+    w3 = ld32_clamped(in, base + 768 + 4 * lane, n);
+}
+// make [q, q+24) readable: base <= q < base + 512 afterwards (q only ever moves forward)
+__device__ __forceinline__ void win_seek(const uint8_t *__restrict__ in, uint32_t n, uint32_t lane,
+                                         uint32_t q, uint32_t &base, uint32_t &w0, uint32_t &w1,
+                                         uint32_t &w2, uint32_t &w3)
+{
+    if (q < base + 512)
+        return;
+    if (q < base + 768) {
+        w0 = w1;
+        w1 = w2;
+        w2 = w3;
+        w3 = ld32_clamped(in, base + 1024 + 4 * lane, n);
+        base += 256;
+    } else {
+        base = q & ~255u;
+        win_load_all(in, n, lane, base, w0, w1, w2, w3);
+    }
+}
+__device__ __forceinline__ uint32_t win_reg(uint32_t j, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    uint32_t r = w0;
+    r = (j == 1) ? w1 : r;
+    r = (j == 2) ? w2 : r;
+    r = (j == 3) ? w3 : r;
+    return r;
+}
+// bytes [q, q+17) as s0..s3 + low byte of s4 (wave-uniform values)
+__device__ __forceinline__ void win_get17(uint32_t q, uint32_t base, uint32_t w0, uint32_t w1, uint32_t w2,
+                                          uint32_t w3, uint32_t &s0, uint32_t &s1, uint32_t &s2,
+                                          uint32_t &s3, uint32_t &s4)
+{
+    const uint32_t o = q - base;
+    const uint32_t k = o >> 2, sh = (o & 3u) * 8u;
+    const uint32_t l = k & 63u, j = k >> 6;
+    uint32_t d0, d1, d2, d3, d4;
+    if (l <= 59) {
+        const uint32_t r = win_reg(j, w0, w1, w2, w3);
+        d0 = __builtin_amdgcn_readlane(r, l);
+        d1 = __builtin_amdgcn_readlane(r, l + 1);
+        d2 = __builtin_amdgcn_readlane(r, l + 2);
+        d3 = __builtin_amdgcn_readlane(r, l + 3);
+        d4 = __builtin_amdgcn_readlane(r, l + 4);
+    } else {
+        d0 = __builtin_amdgcn_readlane(win_reg(k >> 6, w0, w1, w2, w3), k & 63u);
+        d1 = __builtin_amdgcn_readlane(win_reg((k + 1) >> 6, w0, w1, w2, w3), (k + 1) & 63u);
+        d2 = __builtin_amdgcn_readlane(win_reg((k + 2) >> 6, w0, w1, w2, w3), (k + 2) & 63u);
+        d3 = __builtin_amdgcn_readlane(win_reg((k + 3) >> 6, w0, w1, w2, w3), (k + 3) & 63u);
+        d4 = __builtin_amdgcn_readlane(win_reg((k + 4) >> 6, w0, w1, w2, w3), (k + 4) & 63u);
+    }
+    s0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+    s1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
+    s2 = (uint32_t)((((uint64_t)d3 << 32) | d2) >> sh);
+    s3 = (uint32_t)((((uint64_t)d4 << 32) | d3) >> sh);
+    s4 = d4 >> sh;
+}
+
+// select among six registers by a wave-uniform index (kept as scalars on purpose: an array here
+// is turned into a scratch lookup by the compiler)
+__device__ __forceinline__ uint32_t sel6(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t r4,
+                                         uint32_t r5, uint32_t b)
+{
+    uint32_t v = r0;
+    v = (b == 1) ? r1 : v;
+    v = (b == 2) ? r2 : v;
+    v = (b == 3) ? r3 : v;
+    v = (b == 4) ? r4 : v;
+    v = (b == 5) ? r5 : v;
+    return v;
+}
+
 // ------------------------------------------------------------------------ compress kernel
 
 __global__ __launch_bounds__(64) void compress_blocks_kernel(
@@ -227,8 +352,10 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
     uint32_t *__restrict__ out_len, uint32_t flags)
 {
     // The whole LDS budget of this kernel: 32 KiB -> 5 workgroups per CU.
-    __shared__ __attribute__((aligned(16))) uint16_t table_mem[kMaxTable];
-    volatile uint16_t *tab = table_mem;  // volatile: LDS write->read-back must not be forwarded
+    // NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
+    // loads/stores with a vmcnt(0) wait after each.  The one place that needs "really re-read
+    // memory" (other lanes of the same ds_write may have won the bucket) uses a compiler barrier.
+    __shared__ __attribute__((aligned(16))) uint16_t tab[kMaxTable];
 
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -265,35 +392,78 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
         return;
     }
 
-    // (a2) zeroed uint16 table, T = clamp(pow2 >= n, 256, 16384)
-    uint32_t log2T = 8;
-    while (log2T < 14 && (1u << log2T) < n)
-        log2T++;
-    const uint32_t shift = 32 - log2T;
-    {
-        const uint32_t nvec = (1u << log2T) >> 3;  // 16-byte chunks
-        u32x4 z = {0, 0, 0, 0};
-        for (uint32_t i = lane; i < nvec; i += 64)
-            reinterpret_cast<u32x4 *>(table_mem)[i] = z;
-    }
-
     uint32_t next_emit = 0;
     if (n >= kInputMargin) {
         const uint32_t ip_limit = n - kInputMargin;
+
+        // probe schedule in registers: lane l holds off[64*j + l] and off[64*j + l + 1]
+        const uint32_t *po = g_probe.off + lane;
+        const uint32_t Pr0 = po[0], Pr1 = po[64], Pr2 = po[128], Pr3 = po[192], Pr4 = po[256], Pr5 = po[320];
+        const uint32_t Pn0 = po[1], Pn1 = po[65], Pn2 = po[129], Pn3 = po[193], Pn4 = po[257], Pn5 = po[321];
+        // The first scan of a block starts at 1: fetch the shingles of ALL its probe positions now
+        // (one HBM latency for the whole block instead of one per batch when nothing matches).
+        u32x4 a = {0, 0, 0, 0};
+        if (1 + Pn0 <= ip_limit)
+            a = ld128(in + 1 + Pr0);
+        uint32_t pv1 = 0, pv2 = 0, pv3 = 0, pv4 = 0;
+        if (1 + Pn1 <= ip_limit) pv1 = ld32(in + 1 + Pr1);
+        if (1 + Pn2 <= ip_limit) pv2 = ld32(in + 1 + Pr2);
+        if (1 + Pn3 <= ip_limit) pv3 = ld32(in + 1 + Pr3);
+        if (1 + Pn4 <= ip_limit) pv4 = ld32(in + 1 + Pr4);
+        uint32_t wbase = 0, w0, w1, w2, w3;
+        win_load_all(in, n, lane, wbase, w0, w1, w2, w3);
+        uint32_t lead_byte = in[0];
+        (void)lead_byte;
+
+        // (a2) zeroed uint16 table, T = clamp(pow2 >= n, 256, 16384)
+        uint32_t log2T = 8;
+        while (log2T < 14 && (1u << log2T) < n)
+            log2T++;
+        const uint32_t shift = 32 - log2T;
+        {
+            const uint32_t nvec = (1u << log2T) >> 3;  // 16-byte chunks
+            u32x4 z = {0, 0, 0, 0};
+            for (uint32_t i = lane; i < nvec; i += 64)
+                reinterpret_cast<u32x4 *>(tab)[i] = z;
+        }
+
         uint32_t scan_base = 1;  // position of probe 0 of the current scan (skip == 32 there)
         uint32_t n0 = 0;         // probes of this scan already done
-        for (;;) {
+        bool first_scan = true;  // pv[] belongs to the scan that starts at 1
+        bool pre = true;         // `a` already holds this batch's 16-byte windows
+        bool done = false;
+        while (!done) {
             // ---------------- (a3) one speculative batch of up to 64 scan probes
-            const uint32_t idx = n0 + lane;
-            const uint32_t p = scan_base + g_probe.off[idx];
-            const uint32_t pn = scan_base + g_probe.off[idx + 1];
+            uint32_t p, pn;
+            const bool aligned = (n0 & 63u) == 0 && n0 < 384;
+            const uint32_t bsel = n0 >> 6;
+            if (aligned) {
+                p = scan_base + sel6(Pr0, Pr1, Pr2, Pr3, Pr4, Pr5, bsel);
+                pn = scan_base + sel6(Pn0, Pn1, Pn2, Pn3, Pn4, Pn5, bsel);
+            } else {
+                uint32_t idx = n0 + lane;
+                idx = idx < kProbeEntries - 2 ? idx : kProbeEntries - 2;
+                p = scan_base + g_probe.off[idx];
+                pn = scan_base + g_probe.off[idx + 1];
+            }
             const bool valid = pn <= ip_limit;  // the reference checks next_ip before probing ip
-            uint32_t v = 0, h = 0, cand = 0, w = p & 0xffffu;
+            bool have_win = true;               // a.y..a.w hold bytes p+4..p+15
+            if (!pre) {
+                if (first_scan && aligned && bsel >= 1 && bsel <= 4) {
+                    a.x = (bsel == 1) ? pv1 : (bsel == 2) ? pv2 : (bsel == 3) ? pv3 : pv4;
+                    have_win = false;
+                } else if (valid) {
+                    a = ld128(in + p);
+                }
+            }
+            pre = false;
+            const uint32_t v = a.x;
+            uint32_t h = 0, cand = 0, w = p & 0xffffu;
             if (valid) {
-                v = ld32(in + p);
                 h = (v * kHashMul) >> shift;
                 cand = tab[h];
                 tab[h] = (uint16_t)p;
+                asm volatile("" ::: "memory");  // the read-back below must come from LDS, not from p
                 w = tab[h];
             }
             const uint32_t nvalid = (uint32_t)__builtin_popcountll(__ballot(valid));  // valid is a prefix
@@ -318,8 +488,10 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
             }
             const uint32_t nact = nvalid < cut ? nvalid : cut;
             const bool act = lane < nact;
-            const uint32_t cv = act ? ld32(in + cand) : 0;
-            const uint64_t hits = __ballot(act && cv == v);
+            u32x4 c = {0, 0, 0, 0};
+            if (act)
+                c = ld128(in + cand);  // cand < p <= n-16: in bounds
+            const uint64_t hits = __ballot(act && c.x == v);
             if (hits == 0) {
                 if (nact == nvalid && nvalid < 64)
                     break;  // ran into ip_limit: remainder
@@ -331,32 +503,55 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
                 tab[h] = (uint16_t)cand;  // probes behind the first hit never happened
             uint32_t ip = lane_get(p, f);
             uint32_t cnd = lane_get(cand, f);
+            uint32_t m;
+            if (have_win) {
+                m = lane_get(matchlen16(a.y, a.z, a.w, c.y, c.z, c.w), f);
+                if (m == 16)
+                    m = match_length(in, cnd, ip, n, lane, 16);
+            } else {
+                m = match_length(in, cnd, ip, n, lane, 4);
+            }
 
             // ---------------- (a7) pending literal, then (a5)(a6) chain of copies
-            op = emit_literal(out, op, in + next_emit, ip - next_emit, lane);
-            bool more = true;
+            if (!(flags & 0x100u))
+                op = emit_literal(out, op, in + next_emit, ip - next_emit, lane);
             for (;;) {
-                const uint32_t m = match_length(in, cnd, ip, n, lane);
-                op = emit_copy(out, op, ip - cnd, m, lane);
+                if (!(flags & 0x100u))
+                    op = emit_copy(out, op, ip - cnd, m, lane);
                 ip += m;
                 next_emit = ip;
                 if (ip >= ip_limit) {
-                    more = false;
+                    done = true;
                     break;
                 }
-                const uint64_t x = ld64(in + ip - 1);
-                const uint32_t vprev = (uint32_t)x, vcur = (uint32_t)(x >> 8);
+                // bytes ip-1 .. ip+15 from the register window (no memory round trip)
+                win_seek(in, n, lane, ip - 1, wbase, w0, w1, w2, w3);
+                uint32_t s0, s1, s2, s3, s4;
+                win_get17(ip - 1, wbase, w0, w1, w2, w3, s0, s1, s2, s3, s4);
+                const uint32_t vprev = s0;
+                const uint32_t vcur = (s0 >> 8) | (s1 << 24);
                 tab[(vprev * kHashMul) >> shift] = (uint16_t)(ip - 1);
-                const uint32_t c = (vcur * kHashMul) >> shift;
-                cnd = tab[c];
-                tab[c] = (uint16_t)ip;
-                if (uni(ld32(in + cnd)) != uni(vcur))
+                const uint32_t cb = (vcur * kHashMul) >> shift;
+                cnd = uni(tab[cb]);
+                tab[cb] = (uint16_t)ip;
+                // one round trip: the candidate's 16 bytes, and (speculatively: a miss here ends the
+                // chain) the windows of the next scan batch, which starts at ip+1 with skip = 32
+                const u32x4 cc = ld128(in + cnd);
+                scan_base = ip + 1;  // (a4)
+                n0 = 0;
+                first_scan = false;
+                if (scan_base + Pn0 <= ip_limit)
+                    a = ld128(in + scan_base + Pr0);
+                if (uni(cc.x) != vcur) {
+                    pre = true;
                     break;
+                }
+                const uint32_t t1 = (s1 >> 8) | (s2 << 24), t2 = (s2 >> 8) | (s3 << 24),
+                               t3 = (s3 >> 8) | (s4 << 24);
+                m = matchlen16(uni(cc.y), uni(cc.z), uni(cc.w), t1, t2, t3);
+                if (m == 16)
+                    m = match_length(in, cnd, ip, n, lane, 16);
             }
-            if (!more)
-                break;
-            scan_base = ip + 1;  // (a4) miss after a copy: resume scanning one byte on, skip = 32
-            n0 = 0;
         }
     }
     if (next_emit < n)
