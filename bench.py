@@ -199,6 +199,11 @@ def main():
         k_ms = float(np.mean(main_res["kernel_ms"]))
         algo_bytes = main_res["in_bytes"] + main_res["out_bytes"] + 4 * B  # per launch (this rank)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/pmc_summary.py)
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_%s_%d.json" % (args.workload, B))
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                traffic = json.load(f).get("hbm_traffic_bytes_per_launch")
         line = {
             "metric": "snappy_compress_input_GBps_64KiB_blocks",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -214,7 +219,8 @@ def main():
             "compression_ratio": round(main_res["in_bytes"] / main_res["out_bytes"], 5),
             "input_frac_of_hbm_peak": round(main_res["in_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": int(traffic) if traffic else None,
                          "kernel": "szk::compress_blocks_kernel", "kernel_ms_avg": round(k_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
             "workloads": extras,
