@@ -27,6 +27,21 @@ namespace szk {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (tools/chainprof.hip compiles this file with -DSZ_PROF): cycle stamps per
+// phase, summed per block into g_prof.  Expands to nothing in the product build.
+#ifdef SZ_PROF
+__device__ unsigned long long g_prof[32];
+#define PROF_DECL unsigned long long pt_ = 0, pacc_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned pcnt_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+#define PROF_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt_) :: "memory"); } while (0)
+#define PROF_LAP(i) do { unsigned long long t2_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
+#define PROF_FLUSH() do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; i_++) { atomicAdd(&g_prof[i_], pacc_[i_]); atomicAdd(&g_prof[16 + i_], (unsigned long long)pcnt_[i_]); } } } while (0)
+#else
+#define PROF_DECL
+#define PROF_START() do { } while (0)
+#define PROF_LAP(i) do { } while (0)
+#define PROF_FLUSH() do { } while (0)
+#endif
+
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxBlock = 65536u;
 static constexpr uint32_t kMaxTable = 16384u;
@@ -261,73 +276,27 @@ __device__ __forceinline__ uint32_t match_length(const uint8_t *__restrict__ in,
     }
 }
 
-// 1 KiB sliding window of the input STREAM side held in registers: lane l keeps the dwords at
-// base + 256*j + 4*l in wj (j = 0..3), base a multiple of 256.  The copy chain reads the bytes at
-// ip-1 .. ip+16 from here with v_readlane instead of a dependent global load; the refill load is
-// issued >= 512 bytes ahead of use.  (Four separate scalars, not a struct/array: see sel6.)
-__device__ __forceinline__ void win_load_all(const uint8_t *__restrict__ in, uint32_t n, uint32_t lane,
-                                             uint32_t base, uint32_t &w0, uint32_t &w1, uint32_t &w2,
-                                             uint32_t &w3)
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+
+// 32 bytes at a WAVE-UNIFORM byte offset of the block, through the scalar unit: `inw` is the
+// block base rounded down to 4 bytes, `q` = byte offset + misalignment.  Both operands live in
+// SGPRs and the input is read-only in this kernel, so this is one s_load_dwordx8 (scalar cache
+// -> L2) whose result needs no v_readfirstlane.  Returns the dwords; the caller funnels by (q&3).
+// (Inline asm: in a kernel this size hipcc does not prove the input unclobbered and falls back to
+// a vector load of a uniform address.  The wait is inside the statement, so the result is
+// complete when the statement ends; the input is never written by this kernel.)
+__device__ __forceinline__ u32x8 sload32(const uint32_t *__restrict__ inw, uint32_t q)
 {
-    w0 = ld32_clamped(in, base + 4 * lane, n);
-    w1 = ld32_clamped(in, base + 256 + 4 * lane, n);
-    w2 = ld32_clamped(in, base + 512 + 4 * lane, n);
-    w3 = ld32_clamped(in, base + 768 + 4 * lane, n);
-}
-// make [q, q+24) readable: base <= q < base + 512 afterwards (q only ever moves forward)
-__device__ __forceinline__ void win_seek(const uint8_t *__restrict__ in, uint32_t n, uint32_t lane,
-                                         uint32_t q, uint32_t &base, uint32_t &w0, uint32_t &w1,
-                                         uint32_t &w2, uint32_t &w3)
-{
-    if (q < base + 512)
-        return;
-    if (q < base + 768) {
-        w0 = w1;
-        w1 = w2;
-        w2 = w3;
-        w3 = ld32_clamped(in, base + 1024 + 4 * lane, n);
-        base += 256;
-    } else {
-        base = q & ~255u;
-        win_load_all(in, n, lane, base, w0, w1, w2, w3);
-    }
-}
-__device__ __forceinline__ uint32_t win_reg(uint32_t j, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
-{
-    uint32_t r = w0;
-    r = (j == 1) ? w1 : r;
-    r = (j == 2) ? w2 : r;
-    r = (j == 3) ? w3 : r;
+    u32x8 r;
+    const uint32_t off = q & ~3u;
+    asm volatile("s_load_dwordx8 %0, %1, %2 offset:0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(r)
+                 : "s"(inw), "s"(off));
     return r;
 }
-// bytes [q, q+17) as s0..s3 + low byte of s4 (wave-uniform values)
-__device__ __forceinline__ void win_get17(uint32_t q, uint32_t base, uint32_t w0, uint32_t w1, uint32_t w2,
-                                          uint32_t w3, uint32_t &s0, uint32_t &s1, uint32_t &s2,
-                                          uint32_t &s3, uint32_t &s4)
+__device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, uint32_t sh)
 {
-    const uint32_t o = q - base;
-    const uint32_t k = o >> 2, sh = (o & 3u) * 8u;
-    const uint32_t l = k & 63u, j = k >> 6;
-    uint32_t d0, d1, d2, d3, d4;
-    if (l <= 59) {
-        const uint32_t r = win_reg(j, w0, w1, w2, w3);
-        d0 = __builtin_amdgcn_readlane(r, l);
-        d1 = __builtin_amdgcn_readlane(r, l + 1);
-        d2 = __builtin_amdgcn_readlane(r, l + 2);
-        d3 = __builtin_amdgcn_readlane(r, l + 3);
-        d4 = __builtin_amdgcn_readlane(r, l + 4);
-    } else {
-        d0 = __builtin_amdgcn_readlane(win_reg(k >> 6, w0, w1, w2, w3), k & 63u);
-        d1 = __builtin_amdgcn_readlane(win_reg((k + 1) >> 6, w0, w1, w2, w3), (k + 1) & 63u);
-        d2 = __builtin_amdgcn_readlane(win_reg((k + 2) >> 6, w0, w1, w2, w3), (k + 2) & 63u);
-        d3 = __builtin_amdgcn_readlane(win_reg((k + 3) >> 6, w0, w1, w2, w3), (k + 3) & 63u);
-        d4 = __builtin_amdgcn_readlane(win_reg((k + 4) >> 6, w0, w1, w2, w3), (k + 4) & 63u);
-    }
-    s0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
-    s1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
-    s2 = (uint32_t)((((uint64_t)d3 << 32) | d2) >> sh);
-    s3 = (uint32_t)((((uint64_t)d4 << 32) | d3) >> sh);
-    s4 = d4 >> sh;
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
 }
 
 // select among six registers by a wave-uniform index (kept as scalars on purpose: an array here
@@ -410,10 +379,10 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
         if (1 + Pn2 <= ip_limit) pv2 = ld32(in + 1 + Pr2);
         if (1 + Pn3 <= ip_limit) pv3 = ld32(in + 1 + Pr3);
         if (1 + Pn4 <= ip_limit) pv4 = ld32(in + 1 + Pr4);
-        uint32_t wbase = 0, w0, w1, w2, w3;
-        win_load_all(in, n, lane, wbase, w0, w1, w2, w3);
-        uint32_t lead_byte = in[0];
-        (void)lead_byte;
+        uint32_t lead_byte = in[0];  // byte at next_emit when a scan starts (first literal byte)
+        // scalar view of the block for the copy chain (wave-uniform addresses)
+        const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+        const uint32_t *__restrict__ inw = reinterpret_cast<const uint32_t *>(in - mis);
 
         // (a2) zeroed uint16 table, T = clamp(pow2 >= n, 256, 16384)
         uint32_t log2T = 8;
@@ -432,8 +401,11 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
         bool first_scan = true;  // pv[] belongs to the scan that starts at 1
         bool pre = true;         // `a` already holds this batch's 16-byte windows
         bool done = false;
+        PROF_DECL
+        PROF_START();
         while (!done) {
             // ---------------- (a3) one speculative batch of up to 64 scan probes
+            PROF_LAP(15);
             uint32_t p, pn;
             const bool aligned = (n0 & 63u) == 0 && n0 < 384;
             const uint32_t bsel = n0 >> 6;
@@ -458,6 +430,7 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
             }
             pre = false;
             const uint32_t v = a.x;
+            PROF_LAP(0);  // batch: positions + window load
             uint32_t h = 0, cand = 0, w = p & 0xffffu;
             if (valid) {
                 h = (v * kHashMul) >> shift;
@@ -488,10 +461,12 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
             }
             const uint32_t nact = nvalid < cut ? nvalid : cut;
             const bool act = lane < nact;
+            PROF_LAP(1);  // batch: hash + LDS lookup/insert/read-back + collision check
             u32x4 c = {0, 0, 0, 0};
             if (act)
                 c = ld128(in + cand);  // cand < p <= n-16: in bounds
             const uint64_t hits = __ballot(act && c.x == v);
+            PROF_LAP(2);  // batch: candidate loads + ballot
             if (hits == 0) {
                 if (nact == nvalid && nvalid < 64)
                     break;  // ran into ip_limit: remainder
@@ -513,46 +488,90 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
             }
 
             // ---------------- (a7) pending literal, then (a5)(a6) chain of copies
-            if (!(flags & 0x100u))
+            PROF_LAP(3);  // hit: rollback, readlanes, match length
+            if (n0 == 0 && have_win && f <= 32) {
+                // The literal is [scan_base-1, p_f) and probes 0..32 of a scan are consecutive bytes:
+                // byte 0 is lead_byte, byte i>0 is the first byte of lane i-1's window.  No load.
+                const uint32_t L = f + 1;  // <= 33: one-byte tag
+                const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.x, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                const uint32_t byte = lane == 0 ? lead_byte : prev;
+                const bool is_tag = lane == L;
+                if (lane <= L)
+                    out[is_tag ? op : op + 1 + lane] = (uint8_t)(is_tag ? (L - 1) << 2 : byte);
+                op += 1 + L;
+            } else {
                 op = emit_literal(out, op, in + next_emit, ip - next_emit, lane);
+            }
+            PROF_LAP(4);  // literal emission
             for (;;) {
                 if (!(flags & 0x100u))
                     op = emit_copy(out, op, ip - cnd, m, lane);
+                PROF_LAP(5);  // copy emission
                 ip += m;
                 next_emit = ip;
                 if (ip >= ip_limit) {
                     done = true;
                     break;
                 }
-                // bytes ip-1 .. ip+15 from the register window (no memory round trip)
-                win_seek(in, n, lane, ip - 1, wbase, w0, w1, w2, w3);
-                uint32_t s0, s1, s2, s3, s4;
-                win_get17(ip - 1, wbase, w0, w1, w2, w3, s0, s1, s2, s3, s4);
-                const uint32_t vprev = s0;
-                const uint32_t vcur = (s0 >> 8) | (s1 << 24);
+                uint32_t vprev, vcur, t1 = 0, t2 = 0, t3 = 0;
+                const bool fast = ip + 31 <= n;  // 32-byte scalar reads stay inside the block
+                if (fast) {
+                    // bytes ip-1 .. ip+15 through the scalar unit
+                    const uint32_t q = ip - 1 + mis, sh = (q & 3u) * 8u;
+                    const u32x8 sv = sload32(inw, q);
+                    vprev = funnel(sv[0], sv[1], sh);
+                    const uint32_t x1 = funnel(sv[1], sv[2], sh), x2 = funnel(sv[2], sv[3], sh),
+                                   x3 = funnel(sv[3], sv[4], sh), x4 = sv[4] >> sh;
+                    vcur = (vprev >> 8) | (x1 << 24);
+                    t1 = (x1 >> 8) | (x2 << 24);
+                    t2 = (x2 >> 8) | (x3 << 24);
+                    t3 = (x3 >> 8) | (x4 << 24);
+                } else {
+                    const uint64_t x = ld64(in + ip - 1);  // ip < n-15
+                    vprev = uni((uint32_t)x);
+                    vcur = uni((uint32_t)(x >> 8));
+                }
+                PROF_LAP(6);  // chain: stream bytes (scalar load)
                 tab[(vprev * kHashMul) >> shift] = (uint16_t)(ip - 1);
                 const uint32_t cb = (vcur * kHashMul) >> shift;
                 cnd = uni(tab[cb]);
                 tab[cb] = (uint16_t)ip;
-                // one round trip: the candidate's 16 bytes, and (speculatively: a miss here ends the
-                // chain) the windows of the next scan batch, which starts at ip+1 with skip = 32
-                const u32x4 cc = ld128(in + cnd);
+                PROF_LAP(7);  // chain: hash + LDS
+                // (speculatively: a miss below ends the chain) the windows of the next scan batch,
+                // which starts at ip+1 with skip = 32, travel with the candidate's bytes
                 scan_base = ip + 1;  // (a4)
                 n0 = 0;
                 first_scan = false;
+                lead_byte = vcur & 0xffu;
                 if (scan_base + Pn0 <= ip_limit)
                     a = ld128(in + scan_base + Pr0);
-                if (uni(cc.x) != vcur) {
+                uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
+                if (fast) {
+                    const uint32_t qc = cnd + mis, shc = (qc & 3u) * 8u;
+                    const u32x8 cv = sload32(inw, qc);  // cnd < ip: in bounds too
+                    c0 = funnel(cv[0], cv[1], shc);
+                    c1 = funnel(cv[1], cv[2], shc);
+                    c2 = funnel(cv[2], cv[3], shc);
+                    c3 = funnel(cv[3], cv[4], shc);
+                } else {
+                    c0 = uni(ld32(in + cnd));
+                }
+                PROF_LAP(8);  // chain: next-batch window issue + candidate bytes (scalar load)
+                if (c0 != vcur) {
                     pre = true;
                     break;
                 }
-                const uint32_t t1 = (s1 >> 8) | (s2 << 24), t2 = (s2 >> 8) | (s3 << 24),
-                               t3 = (s3 >> 8) | (s4 << 24);
-                m = matchlen16(uni(cc.y), uni(cc.z), uni(cc.w), t1, t2, t3);
-                if (m == 16)
-                    m = match_length(in, cnd, ip, n, lane, 16);
+                if (fast) {
+                    m = matchlen16(c1, c2, c3, t1, t2, t3);
+                    if (m == 16)
+                        m = match_length(in, cnd, ip, n, lane, 16);
+                } else {
+                    m = match_length(in, cnd, ip, n, lane, 4);
+                }
+                PROF_LAP(9);  // chain: match length
             }
         }
+        PROF_FLUSH();
     }
     if (next_emit < n)
         op = emit_literal(out, op, in + next_emit, n - next_emit, lane);
