@@ -276,29 +276,6 @@ __device__ __forceinline__ uint32_t match_length(const uint8_t *__restrict__ in,
     }
 }
 
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-
-// 32 bytes at a WAVE-UNIFORM byte offset of the block, through the scalar unit: `inw` is the
-// block base rounded down to 4 bytes, `q` = byte offset + misalignment.  Both operands live in
-// SGPRs and the input is read-only in this kernel, so this is one s_load_dwordx8 (scalar cache
-// -> L2) whose result needs no v_readfirstlane.  Returns the dwords; the caller funnels by (q&3).
-// (Inline asm: in a kernel this size hipcc does not prove the input unclobbered and falls back to
-// a vector load of a uniform address.  The wait is inside the statement, so the result is
-// complete when the statement ends; the input is never written by this kernel.)
-__device__ __forceinline__ u32x8 sload32(const uint32_t *__restrict__ inw, uint32_t q)
-{
-    u32x8 r;
-    const uint32_t off = q & ~3u;
-    asm volatile("s_load_dwordx8 %0, %1, %2 offset:0x0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=s"(r)
-                 : "s"(inw), "s"(off));
-    return r;
-}
-__device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, uint32_t sh)
-{
-    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
-}
-
 // select among six registers by a wave-uniform index (kept as scalars on purpose: an array here
 // is turned into a scratch lookup by the compiler)
 __device__ __forceinline__ uint32_t sel6(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t r4,
@@ -313,17 +290,52 @@ __device__ __forceinline__ uint32_t sel6(uint32_t r0, uint32_t r1, uint32_t r2, 
     return v;
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP (no LDS): Hillis-Steele inside each row of 16,
+// then row_bcast:15 / row_bcast:31 to carry the row totals.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+#define SZ_DPP(v, ctrl, rmask) (uint32_t) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, true)
+    x += SZ_DPP(x, 0x111, 0xf);  // row_shr:1
+    x += SZ_DPP(x, 0x112, 0xf);  // row_shr:2
+    x += SZ_DPP(x, 0x114, 0xf);  // row_shr:4
+    x += SZ_DPP(x, 0x118, 0xf);  // row_shr:8
+    x += SZ_DPP(x, 0x142, 0xa);  // row_bcast:15 -> rows 1,3
+    x += SZ_DPP(x, 0x143, 0xc);  // row_bcast:31 -> rows 2,3
+#undef SZ_DPP
+    return x;
+}
+
+__device__ __forceinline__ uint64_t lanes_below(uint32_t k)  // bits 0..k-1, k in 0..64
+{
+    return k >= 64 ? ~0ull : ((1ull << k) - 1);
+}
+
 // ------------------------------------------------------------------------ compress kernel
+//
+// State between steps (all wave-uniform): P = next position to probe; chain = P is the end of a
+// copy (the reference then inserts P-1 and probes P, snappy's "copy chain"); otherwise a scan is in
+// progress and sc = index of its next probe (probe k sits at scan_base + off[k]); next_emit = start
+// of the pending literal.
+//
+// DENSE WINDOW (sc <= 31: probes 0..31 of a scan advance by one byte).  Lane l takes position W0 + l.  All 64
+// positions are hashed, looked up and compared against their candidate at once; which of them the
+// serial parse actually visits is then a short scalar walk over the hit mask (a hit at lane j with
+// local match length ml sends the parse to lane j+ml, a miss to lane j+1), and the elements of the
+// window are packed by a wave prefix sum.  The lookups are exact because the window is cut before
+// the first lane whose bucket was already used by an earlier lane of the same window.
+//
+// STRIDED BATCH (sc >= 32: the skip heuristic has accelerated).  Lane k takes the k-th future probe
+// of the schedule; the first hit wins and probes behind it are rolled back.
 
 __global__ __launch_bounds__(64) void compress_blocks_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
     uint32_t *__restrict__ out_len, uint32_t flags)
 {
-    // The whole LDS budget of this kernel: 32 KiB -> 5 workgroups per CU.
+    // The whole LDS budget of this kernel is the table: 32 KiB (4 workgroups resident per CU).
     // NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
-    // loads/stores with a vmcnt(0) wait after each.  The one place that needs "really re-read
-    // memory" (other lanes of the same ds_write may have won the bucket) uses a compiler barrier.
+    // loads/stores with a vmcnt(0) wait after each.  The places that need "really re-read memory"
+    // (other lanes of the same ds_write may have won the bucket) use a compiler barrier.
     __shared__ __attribute__((aligned(16))) uint16_t tab[kMaxTable];
 
     const uint32_t lane = threadIdx.x;
@@ -363,26 +375,19 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
 
     uint32_t next_emit = 0;
     if (n >= kInputMargin) {
-        const uint32_t ip_limit = n - kInputMargin;
+        const uint32_t ip_limit = n - kInputMargin;  // positions <= n-16 may be probed
 
         // probe schedule in registers: lane l holds off[64*j + l] and off[64*j + l + 1]
         const uint32_t *po = g_probe.off + lane;
-        const uint32_t Pr0 = po[0], Pr1 = po[64], Pr2 = po[128], Pr3 = po[192], Pr4 = po[256], Pr5 = po[320];
-        const uint32_t Pn0 = po[1], Pn1 = po[65], Pn2 = po[129], Pn3 = po[193], Pn4 = po[257], Pn5 = po[321];
-        // The first scan of a block starts at 1: fetch the shingles of ALL its probe positions now
+        const uint32_t Pr1 = po[64], Pr2 = po[128], Pr3 = po[192], Pr4 = po[256], Pr5 = po[320];
+        const uint32_t Pn1 = po[65], Pn2 = po[129], Pn3 = po[193], Pn4 = po[257], Pn5 = po[321];
+        // The first scan of a block starts at 1: fetch the shingles of its far probe positions now
         // (one HBM latency for the whole block instead of one per batch when nothing matches).
-        u32x4 a = {0, 0, 0, 0};
-        if (1 + Pn0 <= ip_limit)
-            a = ld128(in + 1 + Pr0);
         uint32_t pv1 = 0, pv2 = 0, pv3 = 0, pv4 = 0;
         if (1 + Pn1 <= ip_limit) pv1 = ld32(in + 1 + Pr1);
         if (1 + Pn2 <= ip_limit) pv2 = ld32(in + 1 + Pr2);
         if (1 + Pn3 <= ip_limit) pv3 = ld32(in + 1 + Pr3);
         if (1 + Pn4 <= ip_limit) pv4 = ld32(in + 1 + Pr4);
-        uint32_t lead_byte = in[0];  // byte at next_emit when a scan starts (first literal byte)
-        // scalar view of the block for the copy chain (wave-uniform addresses)
-        const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
-        const uint32_t *__restrict__ inw = reinterpret_cast<const uint32_t *>(in - mis);
 
         // (a2) zeroed uint16 table, T = clamp(pow2 >= n, 256, 16384)
         uint32_t log2T = 8;
@@ -396,41 +401,211 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
                 reinterpret_cast<u32x4 *>(tab)[i] = z;
         }
 
-        uint32_t scan_base = 1;  // position of probe 0 of the current scan (skip == 32 there)
-        uint32_t n0 = 0;         // probes of this scan already done
+        uint32_t P = 1;          // next position to probe
+        bool chain = false;      // P ends a copy: insert P-1, probe P
+        uint32_t sc = 0;         // scan: index of the next probe
+        uint32_t scan_base = 1;  // scan: position of probe 0 (skip == 32 there)
         bool first_scan = true;  // pv[] belongs to the scan that starts at 1
-        bool pre = true;         // `a` already holds this batch's 16-byte windows
-        bool done = false;
         PROF_DECL
         PROF_START();
-        while (!done) {
-            // ---------------- (a3) one speculative batch of up to 64 scan probes
-            PROF_LAP(15);
+        for (;;) {
+            if (chain || sc <= 31) {
+                // =================================================== dense window
+                if (P >= ip_limit)
+                    break;  // remainder
+                const uint32_t first = chain ? 1u : 0u;
+                const uint32_t W0 = P - first;
+                const uint32_t pos = W0 + lane;
+                const bool valid = pos < ip_limit;  // a prefix of the lanes; lane `first` is valid
+                u32x4 a = {0, 0, 0, 0};
+                if (valid)
+                    a = ld128(in + pos);  // pos + 16 <= n
+                const uint32_t h = (a.x * kHashMul) >> shift;
+                PROF_LAP(0);
+                if (chain && lane == 0)
+                    tab[h] = (uint16_t)pos;  // the reference inserts P-1 before it looks P up
+                const bool spec = valid && lane >= first;
+                uint32_t cand = 0, w = pos & 0xffffu;
+                if (spec) {
+                    cand = tab[h];
+                    tab[h] = (uint16_t)pos;
+                    asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
+                    w = tab[h];
+                    asm volatile("" ::: "memory");
+                    tab[h] = (uint16_t)cand;  // nothing is inserted until the walk says so
+                }
+                const uint32_t nvalid = (uint32_t)__builtin_popcountll(__ballot(valid));
+                const uint64_t losers = __ballot(spec && w != (pos & 0xffffu));
+                uint32_t cut = 64;
+                if (losers) {  // some bucket is used twice in this window: stop before the 2nd user
+                    uint64_t L = losers;
+                    while (L) {
+                        const uint32_t hv = lane_get(h, ctz64(L));
+                        const uint64_t G = __ballot(spec && h == hv);
+                        L &= ~G;
+                        const uint64_t G2 = G & (G - 1);
+                        const uint32_t second = ctz64(G2);
+                        cut = second < cut ? second : cut;
+                    }
+                }
+                const uint32_t lim = nvalid < cut ? nvalid : cut;  // lanes [first, lim) can be probed
+                const bool usable = spec && lane < lim;
+                PROF_LAP(1);
+                u32x4 c = {0, 0, 0, 0};
+                if (usable)
+                    c = ld128(in + cand);  // cand < pos
+                const bool hit = usable && c.x == a.x;
+                const uint32_t ml = matchlen16(a.y, a.z, a.w, c.y, c.z, c.w);  // 4..16 where hit
+                const uint64_t Hm = __ballot(hit);
+                const uint64_t E16 = __ballot(hit && ml == 16);
+                PROF_LAP(2);
+
+                // ---- scalar walk over the hit mask: which lanes does the serial parse visit?
+                uint64_t V = 0;    // probed lanes (their positions get inserted)
+                uint64_t Hp = 0;   // hits on the path
+                uint64_t Ins = 0;  // lanes inserted without being probed (position before a chain probe)
+                uint32_t j = first;
+                bool ch = chain;
+                uint32_t s = sc;
+                uint32_t long_lane = 64;  // hit whose match runs past 16 bytes: finished below
+                bool to_strided = false;
+                uint32_t lit_lane = 64;  // lane where the literal that is open at exit began
+                while (j < lim) {
+                    const uint64_t Hrem = Hm >> j;
+                    const uint32_t k = Hrem ? ctz64(Hrem) : 64u;  // misses before the next hit
+                    const uint32_t budget = ch ? 32u : 31u - s;   // lanes left before probe 32 (step 2)
+                    const uint32_t avail = lim - j;
+                    if (k <= budget && k < avail) {
+                        const uint32_t jh = j + k;
+                        V |= lanes_below(k + 1) << j;
+                        Hp |= 1ull << jh;
+                        lit_lane = 64;
+                        ch = true;
+                        s = 0;
+                        if ((E16 >> jh) & 1) {
+                            long_lane = jh;
+                            break;
+                        }
+                        const uint32_t jn = jh + lane_get(ml, jh);
+                        if (jn < lim)
+                            Ins |= 1ull << (jn - 1);
+                        j = jn;
+                    } else if (k > budget && budget < avail) {
+                        // the scan reaches probe 32 (step 2) inside the window: leave dense mode
+                        V |= lanes_below(budget + 1) << j;
+                        if (ch) {
+                            lit_lane = j;
+                            scan_base = W0 + j + 1;
+                        }
+                        ch = false;
+                        s = 32;
+                        to_strided = true;
+                        break;
+                    } else {  // misses up to the end of the usable lanes
+                        V |= lanes_below(avail) << j;
+                        if (ch) {
+                            lit_lane = j;
+                            scan_base = W0 + j + 1;
+                            s = avail - 1;
+                        } else {
+                            s += avail;
+                        }
+                        ch = false;
+                        j = lim;
+                    }
+                }
+                PROF_LAP(3);
+
+                // ---- commit the inserts of the visited path (distinct buckets below `cut`)
+                if (((V | Ins) >> lane) & 1)
+                    tab[h] = (uint16_t)pos;
+
+                // ---- emit the elements closed inside this window
+                if (Hp) {
+                    const uint32_t jfirst = ctz64(Hp);
+                    const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hp);
+                    if (!chain)  // a literal was open on entry (it began before W0): it ends at the first hit
+                        op = emit_literal(out, op, in + next_emit, W0 + jfirst - next_emit, lane);
+                    uint64_t Lit = V & ~Hp & lanes_below(jlast);
+                    if (!chain)
+                        Lit &= ~lanes_below(jfirst);
+                    const bool is_lit = (Lit >> lane) & 1;
+                    const bool is_hit = (Hp >> lane) & 1;
+                    const bool run_start = is_lit && !((lane > 0) && ((Lit >> (lane - 1)) & 1));
+                    // literal length of the run starting here = distance to the next hit on the path
+                    const uint64_t hp_after = Hp >> lane;
+                    const uint32_t runlen = (uint32_t)__builtin_ctzll(hp_after | (1ull << 63));
+                    const uint32_t off = pos - cand;
+                    const bool short_form = ml < 12 && off < 2048;
+                    uint32_t cnt = 0, word = 0;
+                    if (is_lit) {
+                        cnt = run_start ? 2 : 1;
+                        word = run_start ? (((runlen - 1) << 2) | ((a.x & 0xffu) << 8)) : (a.x & 0xffu);
+                    } else if (is_hit && lane != long_lane) {
+                        cnt = short_form ? 2 : 3;
+                        word = short_form ? (1u | ((ml - 4) << 2) | ((off >> 8) << 5) | ((off & 0xffu) << 8))
+                                          : (2u | ((ml - 1) << 2) | (off << 8));
+                    }
+                    const uint32_t incl = wave_inclusive_sum(cnt);
+                    uint8_t *o = out + op + (incl - cnt);
+                    if (cnt >= 1) o[0] = (uint8_t)word;
+                    if (cnt >= 2) o[1] = (uint8_t)(word >> 8);
+                    if (cnt >= 3) o[2] = (uint8_t)(word >> 16);
+                    op += lane_get(incl, 63);
+                }
+                PROF_LAP(4);
+
+                // ---- next state
+                if (long_lane < 64) {
+                    const uint32_t ip = W0 + long_lane, cnd = lane_get(cand, long_lane);
+                    const uint32_t m = match_length(in, cnd, ip, n, lane, 16);
+                    op = emit_copy(out, op, ip - cnd, m, lane);
+                    P = ip + m;
+                    chain = true;
+                    next_emit = P;
+                } else {
+                    P = W0 + j;
+                    if (to_strided)
+                        P = scan_base + 32;  // position of probe 32 (the strided code recomputes it)
+                    chain = ch;
+                    sc = s;
+                    if (ch)
+                        next_emit = P;
+                    else if (lit_lane < 64)
+                        next_emit = W0 + lit_lane;
+                }
+                first_scan = first_scan && !Hp && (scan_base == 1);
+                PROF_LAP(5);
+                continue;
+            }
+
+            // ======================================================= strided batch (sc >= 32)
+            const uint32_t n0 = sc;
             uint32_t p, pn;
             const bool aligned = (n0 & 63u) == 0 && n0 < 384;
             const uint32_t bsel = n0 >> 6;
+            uint32_t cap = 64;  // lanes allowed in this batch
             if (aligned) {
-                p = scan_base + sel6(Pr0, Pr1, Pr2, Pr3, Pr4, Pr5, bsel);
-                pn = scan_base + sel6(Pn0, Pn1, Pn2, Pn3, Pn4, Pn5, bsel);
+                p = scan_base + sel6(0, Pr1, Pr2, Pr3, Pr4, Pr5, bsel);
+                pn = scan_base + sel6(0, Pn1, Pn2, Pn3, Pn4, Pn5, bsel);
             } else {
                 uint32_t idx = n0 + lane;
                 idx = idx < kProbeEntries - 2 ? idx : kProbeEntries - 2;
                 p = scan_base + g_probe.off[idx];
                 pn = scan_base + g_probe.off[idx + 1];
+                cap = 64 - (n0 & 63u);  // realign to the register-resident schedule
             }
-            const bool valid = pn <= ip_limit;  // the reference checks next_ip before probing ip
-            bool have_win = true;               // a.y..a.w hold bytes p+4..p+15
-            if (!pre) {
-                if (first_scan && aligned && bsel >= 1 && bsel <= 4) {
-                    a.x = (bsel == 1) ? pv1 : (bsel == 2) ? pv2 : (bsel == 3) ? pv3 : pv4;
-                    have_win = false;
-                } else if (valid) {
-                    a = ld128(in + p);
-                }
+            const bool valid = pn <= ip_limit && lane < cap;  // the reference checks next_ip before probing ip
+            const bool limited = __ballot(pn > ip_limit && lane < cap) != 0;
+            u32x4 a = {0, 0, 0, 0};
+            bool have_win = true;  // a.y..a.w hold bytes p+4..p+15
+            if (first_scan && aligned && bsel >= 1 && bsel <= 4) {
+                a.x = (bsel == 1) ? pv1 : (bsel == 2) ? pv2 : (bsel == 3) ? pv3 : pv4;
+                have_win = false;
+            } else if (valid) {
+                a = ld128(in + p);
             }
-            pre = false;
             const uint32_t v = a.x;
-            PROF_LAP(0);  // batch: positions + window load
             uint32_t h = 0, cand = 0, w = p & 0xffffu;
             if (valid) {
                 h = (v * kHashMul) >> shift;
@@ -461,23 +636,22 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
             }
             const uint32_t nact = nvalid < cut ? nvalid : cut;
             const bool act = lane < nact;
-            PROF_LAP(1);  // batch: hash + LDS lookup/insert/read-back + collision check
             u32x4 c = {0, 0, 0, 0};
             if (act)
                 c = ld128(in + cand);  // cand < p <= n-16: in bounds
             const uint64_t hits = __ballot(act && c.x == v);
-            PROF_LAP(2);  // batch: candidate loads + ballot
+            PROF_LAP(6);
             if (hits == 0) {
-                if (nact == nvalid && nvalid < 64)
+                if (nact == nvalid && limited)
                     break;  // ran into ip_limit: remainder
-                n0 += nact;
+                sc = n0 + nact;
                 continue;
             }
             const uint32_t f = ctz64(hits);
             if (act && lane > f)
                 tab[h] = (uint16_t)cand;  // probes behind the first hit never happened
-            uint32_t ip = lane_get(p, f);
-            uint32_t cnd = lane_get(cand, f);
+            const uint32_t ip = lane_get(p, f);
+            const uint32_t cnd = lane_get(cand, f);
             uint32_t m;
             if (have_win) {
                 m = lane_get(matchlen16(a.y, a.z, a.w, c.y, c.z, c.w), f);
@@ -486,90 +660,15 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
             } else {
                 m = match_length(in, cnd, ip, n, lane, 4);
             }
-
-            // ---------------- (a7) pending literal, then (a5)(a6) chain of copies
-            PROF_LAP(3);  // hit: rollback, readlanes, match length
-            if (n0 == 0 && have_win && f <= 32) {
-                // The literal is [scan_base-1, p_f) and probes 0..32 of a scan are consecutive bytes:
-                // byte 0 is lead_byte, byte i>0 is the first byte of lane i-1's window.  No load.
-                const uint32_t L = f + 1;  // <= 33: one-byte tag
-                const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.x, 0x138, 0xf, 0xf, false);  // wave_shr:1
-                const uint32_t byte = lane == 0 ? lead_byte : prev;
-                const bool is_tag = lane == L;
-                if (lane <= L)
-                    out[is_tag ? op : op + 1 + lane] = (uint8_t)(is_tag ? (L - 1) << 2 : byte);
-                op += 1 + L;
-            } else {
-                op = emit_literal(out, op, in + next_emit, ip - next_emit, lane);
-            }
-            PROF_LAP(4);  // literal emission
-            for (;;) {
-                if (!(flags & 0x100u))
-                    op = emit_copy(out, op, ip - cnd, m, lane);
-                PROF_LAP(5);  // copy emission
-                ip += m;
-                next_emit = ip;
-                if (ip >= ip_limit) {
-                    done = true;
-                    break;
-                }
-                uint32_t vprev, vcur, t1 = 0, t2 = 0, t3 = 0;
-                const bool fast = ip + 31 <= n;  // 32-byte scalar reads stay inside the block
-                if (fast) {
-                    // bytes ip-1 .. ip+15 through the scalar unit
-                    const uint32_t q = ip - 1 + mis, sh = (q & 3u) * 8u;
-                    const u32x8 sv = sload32(inw, q);
-                    vprev = funnel(sv[0], sv[1], sh);
-                    const uint32_t x1 = funnel(sv[1], sv[2], sh), x2 = funnel(sv[2], sv[3], sh),
-                                   x3 = funnel(sv[3], sv[4], sh), x4 = sv[4] >> sh;
-                    vcur = (vprev >> 8) | (x1 << 24);
-                    t1 = (x1 >> 8) | (x2 << 24);
-                    t2 = (x2 >> 8) | (x3 << 24);
-                    t3 = (x3 >> 8) | (x4 << 24);
-                } else {
-                    const uint64_t x = ld64(in + ip - 1);  // ip < n-15
-                    vprev = uni((uint32_t)x);
-                    vcur = uni((uint32_t)(x >> 8));
-                }
-                PROF_LAP(6);  // chain: stream bytes (scalar load)
-                tab[(vprev * kHashMul) >> shift] = (uint16_t)(ip - 1);
-                const uint32_t cb = (vcur * kHashMul) >> shift;
-                cnd = uni(tab[cb]);
-                tab[cb] = (uint16_t)ip;
-                PROF_LAP(7);  // chain: hash + LDS
-                // (speculatively: a miss below ends the chain) the windows of the next scan batch,
-                // which starts at ip+1 with skip = 32, travel with the candidate's bytes
-                scan_base = ip + 1;  // (a4)
-                n0 = 0;
-                first_scan = false;
-                lead_byte = vcur & 0xffu;
-                if (scan_base + Pn0 <= ip_limit)
-                    a = ld128(in + scan_base + Pr0);
-                uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
-                if (fast) {
-                    const uint32_t qc = cnd + mis, shc = (qc & 3u) * 8u;
-                    const u32x8 cv = sload32(inw, qc);  // cnd < ip: in bounds too
-                    c0 = funnel(cv[0], cv[1], shc);
-                    c1 = funnel(cv[1], cv[2], shc);
-                    c2 = funnel(cv[2], cv[3], shc);
-                    c3 = funnel(cv[3], cv[4], shc);
-                } else {
-                    c0 = uni(ld32(in + cnd));
-                }
-                PROF_LAP(8);  // chain: next-batch window issue + candidate bytes (scalar load)
-                if (c0 != vcur) {
-                    pre = true;
-                    break;
-                }
-                if (fast) {
-                    m = matchlen16(c1, c2, c3, t1, t2, t3);
-                    if (m == 16)
-                        m = match_length(in, cnd, ip, n, lane, 16);
-                } else {
-                    m = match_length(in, cnd, ip, n, lane, 4);
-                }
-                PROF_LAP(9);  // chain: match length
-            }
+            // (a7) pending literal, (a6) the copy; then the copy chain continues in a dense window
+            op = emit_literal(out, op, in + next_emit, ip - next_emit, lane);
+            op = emit_copy(out, op, ip - cnd, m, lane);
+            P = ip + m;
+            chain = true;
+            sc = 0;
+            next_emit = P;
+            first_scan = false;
+            PROF_LAP(7);
         }
         PROF_FLUSH();
     }
