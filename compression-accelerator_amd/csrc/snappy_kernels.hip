@@ -470,6 +470,53 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
                 uint32_t long_lane = 64;  // hit whose match runs past 16 bytes: finished below
                 bool to_strided = false;
                 uint32_t lit_lane = 64;  // lane where the literal that is open at exit began
+
+                // Can a scan of this window reach probe 32 (where the step becomes 2)?  Only through 32
+                // misses in a row: a run of 32 hit-free lanes, or the misses carried in plus those
+                // before the first hit.  Almost never in compressible data -> lean walk.
+                const uint64_t range = lanes_below(lim) & ~(uint64_t)first;
+                uint64_t z = ~Hm & range;
+                z &= z >> 1;
+                z &= z >> 2;
+                z &= z >> 4;
+                z &= z >> 8;
+                z &= z >> 16;
+                const uint32_t lead = (Hm ? ctz64(Hm) : lim) - first;  // misses before the first hit
+                if (z == 0 && (chain || sc + lead <= 31)) {
+                    const uint32_t mlw = ml == 16 ? 64u : ml;  // a long match ends the window
+                    uint32_t jh = 64;
+                    for (;;) {
+                        const uint64_t t = Hm >> j;
+                        if (t == 0)
+                            break;
+                        const uint32_t k = ctz64(t);
+                        jh = j + k;
+                        V |= lanes_below(k + 1) << j;
+                        Hp |= 1ull << jh;
+                        const uint32_t jn = jh + lane_get(mlw, jh);
+                        j = jn;
+                        if (jn >= lim)
+                            break;
+                        Ins |= 1ull << (jn - 1);
+                    }
+                    if (j < lim) {  // trailing misses up to the end of the usable lanes
+                        V |= lanes_below(lim - j) << j;
+                        if (Hp || chain) {
+                            lit_lane = j;
+                            scan_base = W0 + j + 1;
+                            s = lim - j - 1;
+                        } else {
+                            s = sc + lim - j;
+                        }
+                        ch = false;
+                        j = lim;
+                    } else {
+                        ch = true;
+                        s = 0;
+                        if ((E16 >> jh) & 1)
+                            long_lane = jh;
+                    }
+                } else
                 while (j < lim) {
                     const uint64_t Hrem = Hm >> j;
                     const uint32_t k = Hrem ? ctz64(Hrem) : 64u;  // misses before the next hit
