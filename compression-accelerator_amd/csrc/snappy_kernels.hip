@@ -129,6 +129,21 @@ __device__ __forceinline__ uint32_t matchlen16(uint32_t a1, uint32_t a2, uint32_
     return m;
 }
 
+// Same over 32 bytes (second halves a2/b2); 4..32.
+__device__ __forceinline__ uint32_t matchlen32(const u32x4 &a, const u32x4 &a2, const u32x4 &b, const u32x4 &b2)
+{
+    uint32_t m = 32;
+    uint32_t d;
+    d = a2.w ^ b2.w; if (d) m = 28 + (__builtin_ctz(d) >> 3);
+    d = a2.z ^ b2.z; if (d) m = 24 + (__builtin_ctz(d) >> 3);
+    d = a2.y ^ b2.y; if (d) m = 20 + (__builtin_ctz(d) >> 3);
+    d = a2.x ^ b2.x; if (d) m = 16 + (__builtin_ctz(d) >> 3);
+    d = a.w ^ b.w; if (d) m = 12 + (__builtin_ctz(d) >> 3);
+    d = a.z ^ b.z; if (d) m = 8 + (__builtin_ctz(d) >> 3);
+    d = a.y ^ b.y; if (d) m = 4 + (__builtin_ctz(d) >> 3);
+    return m;
+}
+
 // Cooperative byte copy by one wave, dst-aligned 16-byte stores in the bulk; long copies stream
 // with non-temporal loads/stores, 8 KiB in flight.
 __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s,
@@ -417,9 +432,12 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
                 const uint32_t W0 = P - first;
                 const uint32_t pos = W0 + lane;
                 const bool valid = pos < ip_limit;  // a prefix of the lanes; lane `first` is valid
-                u32x4 a = {0, 0, 0, 0};
+                u32x4 a = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+                const bool wide = pos + 32 <= n;  // bytes 16..31 readable (a prefix of the lanes too)
                 if (valid)
                     a = ld128(in + pos);  // pos + 16 <= n
+                if (wide)
+                    a2 = ld128(in + pos + 16);
                 const uint32_t h = (a.x * kHashMul) >> shift;
                 PROF_LAP(0);
                 if (chain && lane == 0)
@@ -451,13 +469,18 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
                 const uint32_t lim = nvalid < cut ? nvalid : cut;  // lanes [first, lim) can be probed
                 const bool usable = spec && lane < lim;
                 PROF_LAP(1);
-                u32x4 c = {0, 0, 0, 0};
-                if (usable)
+                u32x4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+                if (usable) {
                     c = ld128(in + cand);  // cand < pos
+                    if (wide)
+                        c2 = ld128(in + cand + 16);
+                }
                 const bool hit = usable && c.x == a.x;
-                const uint32_t ml = matchlen16(a.y, a.z, a.w, c.y, c.z, c.w);  // 4..16 where hit
+                // local match length: 4..32 (4..16 near the block end); `mcap` reached = may go on
+                const uint32_t mcap = wide ? 32u : 16u;
+                uint32_t ml = wide ? matchlen32(a, a2, c, c2) : matchlen16(a.y, a.z, a.w, c.y, c.z, c.w);
                 const uint64_t Hm = __ballot(hit);
-                const uint64_t E16 = __ballot(hit && ml == 16);
+                const uint64_t E16 = __ballot(hit && ml == mcap);  // lanes whose match must be extended
                 PROF_LAP(2);
 
                 // ---- scalar walk over the hit mask: which lanes does the serial parse visit?
@@ -483,7 +506,7 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
                 z &= z >> 16;
                 const uint32_t lead = (Hm ? ctz64(Hm) : lim) - first;  // misses before the first hit
                 if (z == 0 && (chain || sc + lead <= 31)) {
-                    const uint32_t mlw = ml == 16 ? 64u : ml;  // a long match ends the window
+                    const uint32_t mlw = ml == mcap ? 64u : ml;  // a long match ends the window
                     uint32_t jh = 64;
                     for (;;) {
                         const uint64_t t = Hm >> j;
@@ -605,7 +628,7 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
                 // ---- next state
                 if (long_lane < 64) {
                     const uint32_t ip = W0 + long_lane, cnd = lane_get(cand, long_lane);
-                    const uint32_t m = match_length(in, cnd, ip, n, lane, 16);
+                    const uint32_t m = match_length(in, cnd, ip, n, lane, lane_get(mcap, long_lane));
                     op = emit_copy(out, op, ip - cnd, m, lane);
                     P = ip + m;
                     chain = true;
