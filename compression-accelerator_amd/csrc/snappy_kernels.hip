@@ -145,7 +145,7 @@ __device__ __forceinline__ uint32_t matchlen32(const u32x4 &a, const u32x4 &a2, 
 }
 
 // Cooperative byte copy by one wave, dst-aligned 16-byte stores in the bulk; long copies stream
-// with non-temporal loads/stores, 8 KiB in flight.
+// with non-temporal loads/stores, 16 KiB in flight.
 __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s,
                                           uint32_t len, uint32_t lane)
 {
@@ -162,14 +162,14 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t
     len -= head;
     const uint32_t nvec = len >> 4;
     uint32_t i = lane;
-    if (nvec >= 512) {
-        for (; i + 448 < nvec; i += 512) {
-            u32x4 q[8];
+    if (nvec >= 1024) {
+        for (; i + 960 < nvec; i += 1024) {
+            u32x4 q[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < 16; u++)
                 q[u] = ld128_nt(s + 16 * (size_t)(i + 64 * u));
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < 16; u++)
                 __builtin_nontemporal_store(q[u], reinterpret_cast<u32x4 *>(d + 16 * (size_t)(i + 64 * u)));
         }
     }
@@ -396,9 +396,14 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
         const uint32_t *po = g_probe.off + lane;
         const uint32_t Pr1 = po[64], Pr2 = po[128], Pr3 = po[192], Pr4 = po[256], Pr5 = po[320];
         const uint32_t Pn1 = po[65], Pn2 = po[129], Pn3 = po[193], Pn4 = po[257], Pn5 = po[321];
+        const uint32_t Pr0b = po[32], Pn0b = po[33];  // probes 32..63 in lanes 0..31 (first strided batch)
         // The first scan of a block starts at 1: fetch the shingles of its far probe positions now
         // (one HBM latency for the whole block instead of one per batch when nothing matches).
-        uint32_t pv1 = 0, pv2 = 0, pv3 = 0, pv4 = 0;
+        uint32_t pv0b = 0, pv1 = 0, pv2 = 0, pv3 = 0, pv4 = 0;
+        u32x4 a_first = {0, 0, 0, 0}, a2_first = {0, 0, 0, 0};  // the first dense window (positions 1..64)
+        if (1 + lane < ip_limit) a_first = ld128(in + 1 + lane);
+        if (1 + lane + 32 <= n) a2_first = ld128(in + 1 + lane + 16);
+        if (lane < 32 && 1 + Pn0b <= ip_limit) pv0b = ld32(in + 1 + Pr0b);
         if (1 + Pn1 <= ip_limit) pv1 = ld32(in + 1 + Pr1);
         if (1 + Pn2 <= ip_limit) pv2 = ld32(in + 1 + Pr2);
         if (1 + Pn3 <= ip_limit) pv3 = ld32(in + 1 + Pr3);
@@ -424,6 +429,8 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
         PROF_DECL
         PROF_START();
         for (;;) {
+            if (flags & 0x200u)  // timing ablation: no match finding at all (one literal)
+                break;
             if (chain || sc <= 31) {
                 // =================================================== dense window
                 if (P >= ip_limit)
@@ -434,10 +441,15 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
                 const bool valid = pos < ip_limit;  // a prefix of the lanes; lane `first` is valid
                 u32x4 a = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
                 const bool wide = pos + 32 <= n;  // bytes 16..31 readable (a prefix of the lanes too)
-                if (valid)
-                    a = ld128(in + pos);  // pos + 16 <= n
-                if (wide)
-                    a2 = ld128(in + pos + 16);
+                if (first_scan && W0 == 1) {  // fetched before the table was zeroed
+                    a = a_first;
+                    a2 = a2_first;
+                } else {
+                    if (valid)
+                        a = ld128(in + pos);  // pos + 16 <= n
+                    if (wide)
+                        a2 = ld128(in + pos + 16);
+                }
                 const uint32_t h = (a.x * kHashMul) >> shift;
                 PROF_LAP(0);
                 if (chain && lane == 0)
@@ -652,12 +664,13 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
             // ======================================================= strided batch (sc >= 32)
             const uint32_t n0 = sc;
             uint32_t p, pn;
-            const bool aligned = (n0 & 63u) == 0 && n0 < 384;
-            const uint32_t bsel = n0 >> 6;
+            const bool aligned = ((n0 & 63u) == 0 && n0 < 384) || n0 == 32;
+            const uint32_t bsel = n0 >> 6;  // 0 only for the half batch n0 == 32
             uint32_t cap = 64;  // lanes allowed in this batch
             if (aligned) {
-                p = scan_base + sel6(0, Pr1, Pr2, Pr3, Pr4, Pr5, bsel);
-                pn = scan_base + sel6(0, Pn1, Pn2, Pn3, Pn4, Pn5, bsel);
+                p = scan_base + sel6(Pr0b, Pr1, Pr2, Pr3, Pr4, Pr5, bsel);
+                pn = scan_base + sel6(Pn0b, Pn1, Pn2, Pn3, Pn4, Pn5, bsel);
+                cap = n0 == 32 ? 32 : 64;
             } else {
                 uint32_t idx = n0 + lane;
                 idx = idx < kProbeEntries - 2 ? idx : kProbeEntries - 2;
@@ -669,8 +682,8 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
             const bool limited = __ballot(pn > ip_limit && lane < cap) != 0;
             u32x4 a = {0, 0, 0, 0};
             bool have_win = true;  // a.y..a.w hold bytes p+4..p+15
-            if (first_scan && aligned && bsel >= 1 && bsel <= 4) {
-                a.x = (bsel == 1) ? pv1 : (bsel == 2) ? pv2 : (bsel == 3) ? pv3 : pv4;
+            if (first_scan && aligned && bsel <= 4) {
+                a.x = (bsel == 0) ? pv0b : (bsel == 1) ? pv1 : (bsel == 2) ? pv2 : (bsel == 3) ? pv3 : pv4;
                 have_win = false;
             } else if (valid) {
                 a = ld128(in + p);
