@@ -342,7 +342,7 @@ __device__ __forceinline__ uint64_t lanes_below(uint32_t k)  // bits 0..k-1, k i
 // STRIDED BATCH (sc >= 32: the skip heuristic has accelerated).  Lane k takes the k-th future probe
 // of the schedule; the first hit wins and probes behind it are rolled back.
 
-__global__ __launch_bounds__(64) void compress_blocks_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void compress_blocks_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
     uint32_t *__restrict__ out_len, uint32_t flags)
@@ -392,6 +392,23 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
     if (n >= kInputMargin) {
         const uint32_t ip_limit = n - kInputMargin;  // positions <= n-16 may be probed
 
+        // Whole-block register prefetch (blocks >= 16 KiB): with one wave per SIMD the register file
+        // is otherwise idle, so all HBM reads of the block are put in flight now and the match
+        // finding below runs under them.  If the block turns out to start with a long literal (it
+        // does when the data is incompressible), that literal is stored straight from these
+        // registers.  Chunk c = 64*u + lane holds literal bytes [bhead + 16c, +16), laid out so that
+        // the stores are 16-byte aligned for the predicted position of the literal (3-byte tag).
+        const bool use_blk = n >= 16384;
+        const uint32_t bhead = (16u - (uint32_t)((uintptr_t)(out + op + 3) & 15u)) & 15u;
+        u32x4 blk[64];
+#pragma unroll
+        for (int u = 0; u < 64; u++) {
+            blk[u] = u32x4{0, 0, 0, 0};
+            if (use_blk && bhead + 16u * (64u * u + lane + 1) <= n)
+                blk[u] = ld128_nt(in + bhead + 16u * (64u * u + lane));
+        }
+        const uint32_t blk_op = op;  // the literal must start here for the prediction to hold
+
         // probe schedule in registers: lane l holds off[64*j + l] and off[64*j + l + 1]
         const uint32_t *po = g_probe.off + lane;
         const uint32_t Pr1 = po[64], Pr2 = po[128], Pr3 = po[192], Pr4 = po[256], Pr5 = po[320];
@@ -420,6 +437,18 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
             for (uint32_t i = lane; i < nvec; i += 64)
                 reinterpret_cast<u32x4 *>(tab)[i] = z;
         }
+
+        // literal emission; a long block-prefix literal is only accounted for here and stored from
+        // the prefetched registers after the main loop (one copy of that code, at a known address)
+        uint32_t big_len = 0;
+        auto emit_lit = [&](uint32_t from, uint32_t len) {
+            if (use_blk && from == 0 && op == blk_op && len >= 4096) {
+                big_len = len;
+                op += 3 + len;
+            } else {
+                op = emit_literal(out, op, in + from, len, lane);
+            }
+        };
 
         uint32_t P = 1;          // next position to probe
         bool chain = false;      // P ends a copy: insert P-1, probe P
@@ -607,7 +636,7 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
                     const uint32_t jfirst = ctz64(Hp);
                     const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hp);
                     if (!chain)  // a literal was open on entry (it began before W0): it ends at the first hit
-                        op = emit_literal(out, op, in + next_emit, W0 + jfirst - next_emit, lane);
+                        emit_lit(next_emit, W0 + jfirst - next_emit);
                     uint64_t Lit = V & ~Hp & lanes_below(jlast);
                     if (!chain)
                         Lit &= ~lanes_below(jfirst);
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
                 m = match_length(in, cnd, ip, n, lane, 4);
             }
             // (a7) pending literal, (a6) the copy; then the copy chain continues in a dense window
-            op = emit_literal(out, op, in + next_emit, ip - next_emit, lane);
+            emit_lit(next_emit, ip - next_emit);
             op = emit_copy(out, op, ip - cnd, m, lane);
             P = ip + m;
             chain = true;
@@ -754,8 +783,30 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(
             PROF_LAP(7);
         }
         PROF_FLUSH();
+        if (next_emit < n) {  // remainder literal
+            emit_lit(next_emit, n - next_emit);
+            next_emit = n;
+        }
+        if (big_len) {  // the block began with a long literal: tag + bytes from the prefetched registers
+            const uint32_t word = (61u << 2) | ((big_len - 1) << 8);  // len >= 257: two length bytes
+            if (lane < 3)
+                out[blk_op + lane] = (uint8_t)(word >> (8 * lane));
+            uint8_t *d = out + blk_op + 3;
+            if (lane < bhead)
+                d[lane] = in[lane];
+            const uint32_t nfull = (big_len - bhead) >> 4;
+            uint8_t *dl = d + bhead + 16u * lane;
+#pragma unroll
+            for (int u = 0; u < 64; u++) {
+                if (64u * u + lane < nfull)
+                    __builtin_nontemporal_store(blk[u], reinterpret_cast<u32x4 *>(dl + 1024 * u));
+            }
+            const uint32_t done = bhead + (nfull << 4);
+            if (lane < big_len - done)
+                d[done + lane] = in[done + lane];
+        }
     }
-    if (next_emit < n)
+    if (next_emit < n)  // blocks shorter than the 15-byte margin are one literal
         op = emit_literal(out, op, in + next_emit, n - next_emit, lane);
     if (lane == 0)
         out_len[b] = op;  // (a9)
