@@ -400,12 +400,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // the stores are 16-byte aligned for the predicted position of the literal (3-byte tag).
         const bool use_blk = n >= 16384;
         const uint32_t bhead = (16u - (uint32_t)((uintptr_t)(out + op + 3) & 15u)) & 15u;
+        const uint32_t nchunk = use_blk ? (n - bhead) >> 10 : 0;  // whole 1 KiB chunks (wave-uniform)
         u32x4 blk[64];
+        {
+            const uint8_t *bp = in + bhead + 16u * lane;
 #pragma unroll
-        for (int u = 0; u < 64; u++) {
-            blk[u] = u32x4{0, 0, 0, 0};
-            if (use_blk && bhead + 16u * (64u * u + lane + 1) <= n)
-                blk[u] = ld128_nt(in + bhead + 16u * (64u * u + lane));
+            for (int u = 0; u < 64; u++) {
+                blk[u] = u32x4{0, 0, 0, 0};
+                if ((uint32_t)u < nchunk)
+                    blk[u] = ld128_nt(bp + 1024 * u);
+            }
         }
         const uint32_t blk_op = op;  // the literal must start here for the prediction to hold
 
@@ -417,9 +421,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // The first scan of a block starts at 1: fetch the shingles of its far probe positions now
         // (one HBM latency for the whole block instead of one per batch when nothing matches).
         uint32_t pv0b = 0, pv1 = 0, pv2 = 0, pv3 = 0, pv4 = 0;
-        u32x4 a_first = {0, 0, 0, 0}, a2_first = {0, 0, 0, 0};  // the first dense window (positions 1..64)
-        if (1 + lane < ip_limit) a_first = ld128(in + 1 + lane);
-        if (1 + lane + 32 <= n) a2_first = ld128(in + 1 + lane + 16);
+        // 32 bytes per lane of the NEXT dense window (positions W .. W+63), loaded one step ahead of
+        // use.  Addresses are clamped to the block instead of predicated; lanes past the limit are
+        // masked out of every decision.
+        const uint32_t last16 = n - 16;  // n >= 15 here; (n == 15: no position is probed at all)
+        u32x4 a = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+        auto load_window = [&](uint32_t W) {
+            const uint32_t q = W + lane;
+            a = ld128(in + (q < last16 ? q : last16));
+            a2 = ld128(in + (q + 16 < last16 ? q + 16 : last16));
+        };
+        if (n >= 16)
+            load_window(1);
         if (lane < 32 && 1 + Pn0b <= ip_limit) pv0b = ld32(in + 1 + Pr0b);
         if (1 + Pn1 <= ip_limit) pv1 = ld32(in + 1 + Pr1);
         if (1 + Pn2 <= ip_limit) pv2 = ld32(in + 1 + Pr2);
@@ -468,18 +481,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 const uint32_t W0 = P - first;
                 const uint32_t pos = W0 + lane;
                 const bool valid = pos < ip_limit;  // a prefix of the lanes; lane `first` is valid
-                u32x4 a = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
-                const bool wide = pos + 32 <= n;  // bytes 16..31 readable (a prefix of the lanes too)
-                if (first_scan && W0 == 1) {  // fetched before the table was zeroed
-                    a = a_first;
-                    a2 = a2_first;
-                } else {
-                    if (valid)
-                        a = ld128(in + pos);  // pos + 16 <= n
-                    if (wide)
-                        a2 = ld128(in + pos + 16);
-                }
-                const uint32_t h = (a.x * kHashMul) >> shift;
+                const bool wide = pos + 32 <= n;    // a2 really holds bytes 16..31 (a prefix too)
+                const uint32_t h = (a.x * kHashMul) >> shift;  // a, a2: loaded by load_window(W0)
                 PROF_LAP(0);
                 if (chain && lane == 0)
                     tab[h] = (uint16_t)pos;  // the reference inserts P-1 before it looks P up
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     asm volatile("" ::: "memory");
                     tab[h] = (uint16_t)cand;  // nothing is inserted until the walk says so
                 }
-                const uint32_t nvalid = (uint32_t)__builtin_popcountll(__ballot(valid));
+                const uint32_t nvalid = ip_limit - W0 < 64 ? ip_limit - W0 : 64;  // W0 < ip_limit
                 const uint64_t losers = __ballot(spec && w != (pos & 0xffffu));
                 uint32_t cut = 64;
                 if (losers) {  // some bucket is used twice in this window: stop before the 2nd user
@@ -510,16 +513,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 const uint32_t lim = nvalid < cut ? nvalid : cut;  // lanes [first, lim) can be probed
                 const bool usable = spec && lane < lim;
                 PROF_LAP(1);
-                u32x4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
-                if (usable) {
-                    c = ld128(in + cand);  // cand < pos
-                    if (wide)
-                        c2 = ld128(in + cand + 16);
-                }
+                // candidates' bytes: unpredicated (cand < pos <= n-16, or 0 for lanes without one)
+                const u32x4 c = ld128(in + cand);
+                const u32x4 c2 = ld128(in + (cand + 16 < last16 ? cand + 16 : last16));
                 const bool hit = usable && c.x == a.x;
                 // local match length: 4..32 (4..16 near the block end); `mcap` reached = may go on
                 const uint32_t mcap = wide ? 32u : 16u;
-                uint32_t ml = wide ? matchlen32(a, a2, c, c2) : matchlen16(a.y, a.z, a.w, c.y, c.z, c.w);
+                uint32_t ml = matchlen32(a, a2, c, c2);
+                ml = ml < mcap ? ml : mcap;
                 const uint64_t Hm = __ballot(hit);
                 const uint64_t E16 = __ballot(hit && ml == mcap);  // lanes whose match must be extended
                 PROF_LAP(2);
@@ -627,6 +628,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
                 PROF_LAP(3);
 
+                // ---- next state, decided before the stores so that the next window's bytes are already
+                // on their way while this window's elements are written
+                const uint32_t abyte = a.x & 0xffu;  // a is about to be reloaded
+                const bool entry_chain = chain;
+                const uint32_t entry_emit = next_emit;
+                if (long_lane == 64) {
+                    P = to_strided ? scan_base + 32 : W0 + j;  // (strided recomputes its positions)
+                    chain = ch;
+                    sc = s;
+                    if (ch)
+                        next_emit = P;
+                    else if (lit_lane < 64)
+                        next_emit = W0 + lit_lane;
+                    if (chain || sc <= 31)
+                        load_window(P - (chain ? 1u : 0u));
+                }
+                first_scan = first_scan && !Hp && (scan_base == 1);
+
                 // ---- commit the inserts of the visited path (distinct buckets below `cut`)
                 if (((V | Ins) >> lane) & 1)
                     tab[h] = (uint16_t)pos;
@@ -635,10 +654,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if (Hp) {
                     const uint32_t jfirst = ctz64(Hp);
                     const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hp);
-                    if (!chain)  // a literal was open on entry (it began before W0): it ends at the first hit
-                        emit_lit(next_emit, W0 + jfirst - next_emit);
+                    if (!entry_chain)  // a literal was open on entry (it began before W0): it ends at the first hit
+                        emit_lit(entry_emit, W0 + jfirst - entry_emit);
                     uint64_t Lit = V & ~Hp & lanes_below(jlast);
-                    if (!chain)
+                    if (!entry_chain)
                         Lit &= ~lanes_below(jfirst);
                     const bool is_lit = (Lit >> lane) & 1;
                     const bool is_hit = (Hp >> lane) & 1;
@@ -651,7 +670,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     uint32_t cnt = 0, word = 0;
                     if (is_lit) {
                         cnt = run_start ? 2 : 1;
-                        word = run_start ? (((runlen - 1) << 2) | ((a.x & 0xffu) << 8)) : (a.x & 0xffu);
+                        word = run_start ? (((runlen - 1) << 2) | (abyte << 8)) : abyte;
                     } else if (is_hit && lane != long_lane) {
                         cnt = short_form ? 2 : 3;
                         word = short_form ? (1u | ((ml - 4) << 2) | ((off >> 8) << 5) | ((off & 0xffu) << 8))
@@ -666,26 +685,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
                 PROF_LAP(4);
 
-                // ---- next state
-                if (long_lane < 64) {
+                if (long_lane < 64) {  // the last hit's match runs past the local window: finish it
                     const uint32_t ip = W0 + long_lane, cnd = lane_get(cand, long_lane);
                     const uint32_t m = match_length(in, cnd, ip, n, lane, lane_get(mcap, long_lane));
                     op = emit_copy(out, op, ip - cnd, m, lane);
                     P = ip + m;
                     chain = true;
+                    sc = 0;
                     next_emit = P;
-                } else {
-                    P = W0 + j;
-                    if (to_strided)
-                        P = scan_base + 32;  // position of probe 32 (the strided code recomputes it)
-                    chain = ch;
-                    sc = s;
-                    if (ch)
-                        next_emit = P;
-                    else if (lit_lane < 64)
-                        next_emit = W0 + lit_lane;
+                    load_window(P - 1);
                 }
-                first_scan = first_scan && !Hp && (scan_base == 1);
                 PROF_LAP(5);
                 continue;
             }
@@ -780,6 +789,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             sc = 0;
             next_emit = P;
             first_scan = false;
+            load_window(P - 1);
             PROF_LAP(7);
         }
         PROF_FLUSH();
@@ -794,16 +804,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             uint8_t *d = out + blk_op + 3;
             if (lane < bhead)
                 d[lane] = in[lane];
-            const uint32_t nfull = (big_len - bhead) >> 4;
+            uint32_t nreg = (big_len - bhead) >> 10;  // whole chunks inside the literal
+            nreg = nreg < nchunk ? nreg : nchunk;
             uint8_t *dl = d + bhead + 16u * lane;
 #pragma unroll
             for (int u = 0; u < 64; u++) {
-                if (64u * u + lane < nfull)
+                if ((uint32_t)u < nreg)
                     __builtin_nontemporal_store(blk[u], reinterpret_cast<u32x4 *>(dl + 1024 * u));
             }
-            const uint32_t done = bhead + (nfull << 4);
-            if (lane < big_len - done)
-                d[done + lane] = in[done + lane];
+            const uint32_t done = bhead + (nreg << 10);  // dst + done is 16-byte aligned
+            if (done < big_len)
+                wave_copy(d + done, in + done, big_len - done, lane);
         }
     }
     if (next_emit < n)  // blocks shorter than the 15-byte margin are one literal
