@@ -556,14 +556,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                             break;
                         const uint32_t k = ctz64(t);
                         jh = j + k;
-                        V |= lanes_below(k + 1) << j;
-                        Hp |= 1ull << jh;
-                        const uint32_t jn = jh + lane_get(mlw, jh);
-                        j = jn;
-                        if (jn >= lim)
+                        V |= ((2ull << k) - 1) << j;  // lanes j..jh (k <= 63)
+                        j = jh + lane_get(mlw, jh);
+                        if (j >= lim)
                             break;
-                        Ins |= 1ull << (jn - 1);
                     }
+                    Hp = Hm & V;
                     if (j < lim) {  // trailing misses up to the end of the usable lanes
                         V |= lanes_below(lim - j) << j;
                         if (Hp || chain) {
@@ -581,6 +579,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         if ((E16 >> jh) & 1)
                             long_lane = jh;
                     }
+                    // the lane before each chain probe is inserted too: it is the last lane of a copy,
+                    // i.e. not visited itself while its successor is
+                    Ins = (V >> 1) & ~V;
                 } else
                 while (j < lim) {
                     const uint64_t Hrem = Hm >> j;
