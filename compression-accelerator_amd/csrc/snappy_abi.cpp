@@ -146,8 +146,10 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
     const size_t longest = in_stride < SZ_BLOCK_SIZE ? in_stride : SZ_BLOCK_SIZE;
     if (dst_stride < sz_max_compressed_length(longest) + 5)
         return SZ_ENOSPC;
-    if (const char *dbg = getenv("SZ_DEBUG_FLAGS"))  // timing ablations only (output is wrong)
+#ifdef SZ_ABLATION  // diagnostic builds only: timing ablations that produce wrong output
+    if (const char *dbg = getenv("SZ_DEBUG_FLAGS"))
         flags |= (uint32_t)strtoul(dbg, nullptr, 0) & 0xff00u;
+#endif
     SZ_HIP(szk::launch_compress_blocks(d_src, in_stride, d_in_len, n_blocks, d_dst, dst_stride, d_out_len,
                                        flags, static_cast<hipStream_t>(stream)));
     return SZ_OK;

@@ -34,11 +34,13 @@ __device__ unsigned long long g_prof[32];
 #define PROF_DECL unsigned long long pt_ = 0, pacc_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned pcnt_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
 #define PROF_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt_) :: "memory"); } while (0)
 #define PROF_LAP(i) do { unsigned long long t2_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
+#define PROF_ADD(i, v) do { pacc_[i] += (unsigned long long)(v); pcnt_[i]++; } while (0)
 #define PROF_FLUSH() do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; i_++) { atomicAdd(&g_prof[i_], pacc_[i_]); atomicAdd(&g_prof[16 + i_], (unsigned long long)pcnt_[i_]); } } } while (0)
 #else
 #define PROF_DECL
 #define PROF_START() do { } while (0)
 #define PROF_LAP(i) do { } while (0)
+#define PROF_ADD(i, v) do { } while (0)
 #define PROF_FLUSH() do { } while (0)
 #endif
 
@@ -471,8 +473,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         PROF_DECL
         PROF_START();
         for (;;) {
+#ifdef SZ_ABLATION
             if (flags & 0x200u)  // timing ablation: no match finding at all (one literal)
                 break;
+#endif
             if (chain || sc <= 31) {
                 // =================================================== dense window
                 if (P >= ip_limit)
@@ -487,148 +491,170 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if (chain && lane == 0)
                     tab[h] = (uint16_t)pos;  // the reference inserts P-1 before it looks P up
                 const bool spec = valid && lane >= first;
-                uint32_t cand = 0, w = pos & 0xffffu;
-                if (spec) {
-                    cand = tab[h];
-                    tab[h] = (uint16_t)pos;
-                    asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
-                    w = tab[h];
-                    asm volatile("" ::: "memory");
-                    tab[h] = (uint16_t)cand;  // nothing is inserted until the walk says so
-                }
+                uint32_t cand = 0;
+                if (spec)
+                    cand = tab[h];  // table as of the start of the window
                 const uint32_t nvalid = ip_limit - W0 < 64 ? ip_limit - W0 : 64;  // W0 < ip_limit
-                const uint64_t losers = __ballot(spec && w != (pos & 0xffffu));
-                uint32_t cut = 64;
-                if (losers) {  // some bucket is used twice in this window: stop before the 2nd user
-                    uint64_t L = losers;
+                PROF_LAP(1);
+                // candidates' bytes: unpredicated (cand < pos <= n-16, or 0 for lanes without one)
+                const u32x4 c = ld128(in + cand);
+                const u32x4 c2 = ld128(in + (cand + 16 < last16 ? cand + 16 : last16));
+                const bool hit = spec && c.x == a.x;
+                // local match length: 4..32 (4..16 near the block end); `mcap` reached = may go on
+                const uint32_t mcap = wide ? 32u : 16u;
+                uint32_t ml = matchlen32(a, a2, c, c2);
+                ml = ml < mcap ? ml : mcap;
+                const uint32_t mlw = ml == mcap ? 64u : ml;  // for the walk: a long match ends the window
+                const uint64_t Hm_all = __ballot(hit);
+                const uint64_t E16 = __ballot(hit && ml == mcap);  // lanes whose match must be extended
+                PROF_LAP(2);
+
+                // ---- scalar walk over the hit mask: which lanes does the serial parse visit?
+                // The lookups above are exact as long as no two INSERTED lanes of the window share a
+                // bucket (the later one should have seen the earlier one).  That is checked after the
+                // fact: commit the inserts, read them back, and in the rare case of a lost write roll
+                // back and redo the walk on the lanes before the second user of the bucket.
+                uint32_t lim = nvalid;  // lanes [first, lim) can be probed
+                uint64_t V, Hp, Ins;    // probed lanes / hits on the path / inserted-only lanes
+                uint32_t j, s, long_lane, lit_lane, new_scan_base;
+                bool ch, to_strided;
+                for (;;) {
+                    const uint64_t Hm = Hm_all & lanes_below(lim);
+                    V = 0;
+                    Hp = 0;
+                    Ins = 0;
+                    j = first;
+                    ch = chain;
+                    s = sc;
+                    long_lane = 64;  // hit whose match runs past the local bytes: finished below
+                    to_strided = false;
+                    lit_lane = 64;   // lane where the literal that is open at exit began
+                    new_scan_base = scan_base;
+                    // Can a scan of this window reach probe 32 (where the step becomes 2)?  Only through
+                    // 32 misses in a row: a run of 32 hit-free lanes, or the misses carried in plus those
+                    // before the first hit.  Almost never in compressible data -> lean walk.
+                    const uint64_t range = lanes_below(lim) & ~(uint64_t)first;
+                    uint64_t z = ~Hm & range;
+                    z &= z >> 1;
+                    z &= z >> 2;
+                    z &= z >> 4;
+                    z &= z >> 8;
+                    z &= z >> 16;
+                    const uint32_t lead = (Hm ? ctz64(Hm) : lim) - first;  // misses before the first hit
+                    if (z == 0 && (chain || sc + lead <= 31)) {
+                        uint32_t jh = 64;
+                        for (;;) {
+                            const uint64_t t = Hm >> j;
+                            if (t == 0)
+                                break;
+                            const uint32_t k = ctz64(t);
+                            jh = j + k;
+                            V |= ((2ull << k) - 1) << j;  // lanes j..jh (k <= 63)
+                            j = jh + lane_get(mlw, jh);
+                            if (j >= lim)
+                                break;
+                        }
+                        Hp = Hm & V;
+                        if (j < lim) {  // trailing misses up to the end of the usable lanes
+                            V |= lanes_below(lim - j) << j;
+                            if (Hp || chain) {
+                                lit_lane = j;
+                                new_scan_base = W0 + j + 1;
+                                s = lim - j - 1;
+                            } else {
+                                s = sc + lim - j;
+                            }
+                            ch = false;
+                            j = lim;
+                        } else {
+                            ch = true;
+                            s = 0;
+                            if ((E16 >> jh) & 1)
+                                long_lane = jh;
+                        }
+                        // the lane before each chain probe is inserted too: it is the last lane of a
+                        // copy, i.e. not visited itself while its successor is
+                        Ins = (V >> 1) & ~V & ~1ull;  // (lane 0 = P-1 in chain mode went in up front)
+                    } else {
+                        while (j < lim) {
+                            const uint64_t Hrem = Hm >> j;
+                            const uint32_t k = Hrem ? ctz64(Hrem) : 64u;  // misses before the next hit
+                            const uint32_t budget = ch ? 32u : 31u - s;   // lanes left before probe 32 (step 2)
+                            const uint32_t avail = lim - j;
+                            if (k <= budget && k < avail) {
+                                const uint32_t jh = j + k;
+                                V |= lanes_below(k + 1) << j;
+                                Hp |= 1ull << jh;
+                                lit_lane = 64;
+                                ch = true;
+                                s = 0;
+                                if ((E16 >> jh) & 1) {
+                                    long_lane = jh;
+                                    break;
+                                }
+                                const uint32_t jn = jh + lane_get(ml, jh);
+                                if (jn < lim)
+                                    Ins |= 1ull << (jn - 1);
+                                j = jn;
+                            } else if (k > budget && budget < avail) {
+                                // the scan reaches probe 32 (step 2) inside the window: leave dense mode
+                                V |= lanes_below(budget + 1) << j;
+                                if (ch) {
+                                    lit_lane = j;
+                                    new_scan_base = W0 + j + 1;
+                                }
+                                ch = false;
+                                s = 32;
+                                to_strided = true;
+                                break;
+                            } else {  // misses up to the end of the usable lanes
+                                V |= lanes_below(avail) << j;
+                                if (ch) {
+                                    lit_lane = j;
+                                    new_scan_base = W0 + j + 1;
+                                    s = avail - 1;
+                                } else {
+                                    s += avail;
+                                }
+                                ch = false;
+                                j = lim;
+                            }
+                        }
+                    }
+                    // ---- commit the inserts of the visited path, then check that none was lost
+                    const bool ins_lane = ((V | Ins) >> lane) & 1;
+                    uint32_t w = pos & 0xffffu;
+                    if (ins_lane) {
+                        tab[h] = (uint16_t)pos;
+                        asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
+                        w = tab[h];
+                    }
+                    uint64_t L = __ballot(ins_lane && w != (pos & 0xffffu));
+                    if (L == 0)
+                        break;
+                    // two inserted lanes share a bucket: roll back (both read the same old entry) and
+                    // keep the lanes before the second user; the redo cannot conflict again
+                    asm volatile("" ::: "memory");
+                    if (ins_lane)
+                        tab[h] = (uint16_t)cand;
+                    uint32_t cut = 64;
                     while (L) {
                         const uint32_t hv = lane_get(h, ctz64(L));
-                        const uint64_t G = __ballot(spec && h == hv);
+                        const uint64_t G = __ballot(ins_lane && h == hv);
                         L &= ~G;
                         const uint64_t G2 = G & (G - 1);
                         const uint32_t second = ctz64(G2);
                         cut = second < cut ? second : cut;
                     }
+                    lim = cut;
                 }
-                const uint32_t lim = nvalid < cut ? nvalid : cut;  // lanes [first, lim) can be probed
-                const bool usable = spec && lane < lim;
-                PROF_LAP(1);
-                // candidates' bytes: unpredicated (cand < pos <= n-16, or 0 for lanes without one)
-                const u32x4 c = ld128(in + cand);
-                const u32x4 c2 = ld128(in + (cand + 16 < last16 ? cand + 16 : last16));
-                const bool hit = usable && c.x == a.x;
-                // local match length: 4..32 (4..16 near the block end); `mcap` reached = may go on
-                const uint32_t mcap = wide ? 32u : 16u;
-                uint32_t ml = matchlen32(a, a2, c, c2);
-                ml = ml < mcap ? ml : mcap;
-                const uint64_t Hm = __ballot(hit);
-                const uint64_t E16 = __ballot(hit && ml == mcap);  // lanes whose match must be extended
-                PROF_LAP(2);
-
-                // ---- scalar walk over the hit mask: which lanes does the serial parse visit?
-                uint64_t V = 0;    // probed lanes (their positions get inserted)
-                uint64_t Hp = 0;   // hits on the path
-                uint64_t Ins = 0;  // lanes inserted without being probed (position before a chain probe)
-                uint32_t j = first;
-                bool ch = chain;
-                uint32_t s = sc;
-                uint32_t long_lane = 64;  // hit whose match runs past 16 bytes: finished below
-                bool to_strided = false;
-                uint32_t lit_lane = 64;  // lane where the literal that is open at exit began
-
-                // Can a scan of this window reach probe 32 (where the step becomes 2)?  Only through 32
-                // misses in a row: a run of 32 hit-free lanes, or the misses carried in plus those
-                // before the first hit.  Almost never in compressible data -> lean walk.
-                const uint64_t range = lanes_below(lim) & ~(uint64_t)first;
-                uint64_t z = ~Hm & range;
-                z &= z >> 1;
-                z &= z >> 2;
-                z &= z >> 4;
-                z &= z >> 8;
-                z &= z >> 16;
-                const uint32_t lead = (Hm ? ctz64(Hm) : lim) - first;  // misses before the first hit
-                if (z == 0 && (chain || sc + lead <= 31)) {
-                    const uint32_t mlw = ml == mcap ? 64u : ml;  // a long match ends the window
-                    uint32_t jh = 64;
-                    for (;;) {
-                        const uint64_t t = Hm >> j;
-                        if (t == 0)
-                            break;
-                        const uint32_t k = ctz64(t);
-                        jh = j + k;
-                        V |= ((2ull << k) - 1) << j;  // lanes j..jh (k <= 63)
-                        j = jh + lane_get(mlw, jh);
-                        if (j >= lim)
-                            break;
-                    }
-                    Hp = Hm & V;
-                    if (j < lim) {  // trailing misses up to the end of the usable lanes
-                        V |= lanes_below(lim - j) << j;
-                        if (Hp || chain) {
-                            lit_lane = j;
-                            scan_base = W0 + j + 1;
-                            s = lim - j - 1;
-                        } else {
-                            s = sc + lim - j;
-                        }
-                        ch = false;
-                        j = lim;
-                    } else {
-                        ch = true;
-                        s = 0;
-                        if ((E16 >> jh) & 1)
-                            long_lane = jh;
-                    }
-                    // the lane before each chain probe is inserted too: it is the last lane of a copy,
-                    // i.e. not visited itself while its successor is
-                    Ins = (V >> 1) & ~V;
-                } else
-                while (j < lim) {
-                    const uint64_t Hrem = Hm >> j;
-                    const uint32_t k = Hrem ? ctz64(Hrem) : 64u;  // misses before the next hit
-                    const uint32_t budget = ch ? 32u : 31u - s;   // lanes left before probe 32 (step 2)
-                    const uint32_t avail = lim - j;
-                    if (k <= budget && k < avail) {
-                        const uint32_t jh = j + k;
-                        V |= lanes_below(k + 1) << j;
-                        Hp |= 1ull << jh;
-                        lit_lane = 64;
-                        ch = true;
-                        s = 0;
-                        if ((E16 >> jh) & 1) {
-                            long_lane = jh;
-                            break;
-                        }
-                        const uint32_t jn = jh + lane_get(ml, jh);
-                        if (jn < lim)
-                            Ins |= 1ull << (jn - 1);
-                        j = jn;
-                    } else if (k > budget && budget < avail) {
-                        // the scan reaches probe 32 (step 2) inside the window: leave dense mode
-                        V |= lanes_below(budget + 1) << j;
-                        if (ch) {
-                            lit_lane = j;
-                            scan_base = W0 + j + 1;
-                        }
-                        ch = false;
-                        s = 32;
-                        to_strided = true;
-                        break;
-                    } else {  // misses up to the end of the usable lanes
-                        V |= lanes_below(avail) << j;
-                        if (ch) {
-                            lit_lane = j;
-                            scan_base = W0 + j + 1;
-                            s = avail - 1;
-                        } else {
-                            s += avail;
-                        }
-                        ch = false;
-                        j = lim;
-                    }
-                }
+                scan_base = new_scan_base;
                 PROF_LAP(3);
 
+                PROF_ADD(10, lim);
+                PROF_ADD(11, lim < nvalid ? 1 : 0);
+                PROF_ADD(12, __builtin_popcountll(Hp));
+                PROF_ADD(13, (long_lane < 64 ? W0 + long_lane : W0 + j) - P);
                 // ---- next state, decided before the stores so that the next window's bytes are already
                 // on their way while this window's elements are written
                 const uint32_t abyte = a.x & 0xffu;  // a is about to be reloaded
@@ -646,10 +672,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         load_window(P - (chain ? 1u : 0u));
                 }
                 first_scan = first_scan && !Hp && (scan_base == 1);
-
-                // ---- commit the inserts of the visited path (distinct buckets below `cut`)
-                if (((V | Ins) >> lane) & 1)
-                    tab[h] = (uint16_t)pos;
 
                 // ---- emit the elements closed inside this window
                 if (Hp) {

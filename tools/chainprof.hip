@@ -11,7 +11,7 @@ int main(int argc, char** argv){
   std::vector<uint8_t> in((size_t)nb*65536); for(size_t i=0;i<in.size();i++) in[i]=h[i%L];
   uint8_t *d_in,*d_out; uint32_t* d_len; hipMalloc(&d_in,in.size()); hipMalloc(&d_out,(size_t)nb*76544); hipMalloc(&d_len,nb*4);
   hipMemcpy(d_in,in.data(),in.size(),hipMemcpyHostToDevice);
-  const char* names[16]={"dense: window load+hash","dense: LDS lookup/readback/cut","dense: cand loads+compare","dense: walk","dense: commit+emit","dense: next state/long match","strided: batch","strided: hit+emit","","","","","","","",""};
+  const char* names[16]={"dense: window load+hash","dense: LDS lookup/readback/cut","dense: cand loads+compare","dense: walk","dense: commit+emit","dense: long match","strided: batch","strided: hit+emit","","","STAT lim (avg)","STAT cut<64 (fraction)","STAT path hits (avg)","STAT advance (avg)","STAT all hits in window (avg)",""};
   for(int rep=0;rep<2;rep++){
     unsigned long long z[32]={0}; hipMemcpyToSymbol(HIP_SYMBOL(szk::g_prof), z, sizeof z);
     hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0);
