@@ -46,7 +46,10 @@ __device__ unsigned long long g_prof[32];
 
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxBlock = 65536u;
-static constexpr uint32_t kMaxTable = 16384u;
+#ifndef SZ_EXPERIMENT_TABLE
+#define SZ_EXPERIMENT_TABLE 16384
+#endif
+static constexpr uint32_t kMaxTable = SZ_EXPERIMENT_TABLE;  // (occupancy experiments shrink it; product: 16384)
 static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
 
 // Probe schedule of the scan loop after a (re)start: off[k] = distance of the k-th probe from the
@@ -344,7 +347,13 @@ __device__ __forceinline__ uint64_t lanes_below(uint32_t k)  // bits 0..k-1, k i
 // STRIDED BATCH (sc >= 32: the skip heuristic has accelerated).  Lane k takes the k-th future probe
 // of the schedule; the first hit wins and probes behind it are rolled back.
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void compress_blocks_kernel(
+#ifdef SZ_EXPERIMENT_GLOBAL_TABLE
+__device__ uint16_t *g_experiment_tables;
+#endif
+#ifndef SZ_EXPERIMENT_WAVES
+#define SZ_EXPERIMENT_WAVES 1
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMENT_WAVES, SZ_EXPERIMENT_WAVES))) void compress_blocks_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
     uint32_t *__restrict__ out_len, uint32_t flags)
@@ -353,7 +362,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
     // loads/stores with a vmcnt(0) wait after each.  The places that need "really re-read memory"
     // (other lanes of the same ds_write may have won the bucket) use a compiler barrier.
+#ifdef SZ_EXPERIMENT_GLOBAL_TABLE  // occupancy experiment only: table in global memory, no LDS
+    uint16_t *tab = g_experiment_tables + (size_t)blockIdx.x * kMaxTable;
+#else
     __shared__ __attribute__((aligned(16))) uint16_t tab[kMaxTable];
+#endif
 
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -423,7 +436,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // does when the data is incompressible), that literal is stored straight from these
         // registers.  Chunk c = 64*u + lane holds literal bytes [bhead + 16c, +16), laid out so that
         // the stores are 16-byte aligned for the predicted position of the literal (3-byte tag).
+#ifdef SZ_EXPERIMENT_NO_BLK
+        const bool use_blk = false;
+#else
         const bool use_blk = n >= 16384;
+#endif
         const uint32_t bhead = (16u - (uint32_t)((uintptr_t)(out + op + 3) & 15u)) & 15u;
         const uint32_t nchunk = use_blk ? (n - bhead) >> 10 : 0;  // whole 1 KiB chunks (wave-uniform)
         u32x4 blk[64];
