@@ -12,9 +12,64 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "snappy_kernels.h"
 
 namespace {
+
+// Dual-wave kernel workspace: one per (device, stream), created on first use and kept for the life
+// of the process (64 MiB on MI355X).  SZ_KERNEL=single disables the dual kernel.
+std::mutex g_dual_mutex;
+std::map<std::pair<int, hipStream_t>, szk::DualScratch> g_dual;
+
+const szk::DualScratch *dual_scratch_for(hipStream_t stream)
+{
+    // SZ_KERNEL=single: never; SZ_KERNEL=dual: whenever there are at least two blocks (tests);
+    // default: when there are enough blocks to give every SIMD two waves.
+    static const int mode = [] {
+        const char *e = getenv("SZ_KERNEL");
+        return !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : 0;
+    }();
+    if (mode == 1)
+        return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return nullptr;
+    std::lock_guard<std::mutex> lock(g_dual_mutex);
+    auto key = std::make_pair(dev, stream);
+    auto it = g_dual.find(key);
+    if (it != g_dual.end())
+        return it->second.tables ? &it->second : nullptr;
+    szk::DualScratch sc{nullptr, nullptr, 0, 0};
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;  // no allocation while a graph is being captured: single kernel this time
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+        sc.n_slots = 4u * (uint32_t)cus;  // four 128-thread workgroups per CU = two waves per SIMD
+        sc.min_blocks = mode == 2 ? 2u : 2u * sc.n_slots;
+        void *t = nullptr, *g = nullptr;
+        if (hipMalloc(&t, (size_t)sc.n_slots * szk::kDualTableBytes) == hipSuccess &&
+            hipMalloc(&g, (size_t)sc.n_slots * sizeof(uint32_t)) == hipSuccess &&
+            hipMemsetAsync(t, 0, (size_t)sc.n_slots * szk::kDualTableBytes, stream) == hipSuccess &&
+            hipMemsetAsync(g, 0, (size_t)sc.n_slots * sizeof(uint32_t), stream) == hipSuccess) {
+            sc.tables = static_cast<uint32_t *>(t);
+            sc.gen = static_cast<uint32_t *>(g);
+        } else {
+            (void)hipGetLastError();
+            if (t) (void)hipFree(t);
+            if (g) (void)hipFree(g);
+        }
+    }
+    auto &slot = g_dual[key];
+    slot = sc;
+    return slot.tables ? &slot : nullptr;
+}
 
 thread_local int tl_hip_error = 0;
 thread_local int tl_rocc_error = 0;
@@ -151,7 +206,8 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
         flags |= (uint32_t)strtoul(dbg, nullptr, 0) & 0xff00u;
 #endif
     SZ_HIP(szk::launch_compress_blocks(d_src, in_stride, d_in_len, n_blocks, d_dst, dst_stride, d_out_len,
-                                       flags, static_cast<hipStream_t>(stream)));
+                                       flags, dual_scratch_for(static_cast<hipStream_t>(stream)),
+                                       static_cast<hipStream_t>(stream)));
     return SZ_OK;
 }
 
@@ -166,6 +222,7 @@ int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t sl
     if (slot_stride < sz_max_compressed_length(longest) + 5)
         return SZ_ENOSPC;
     SZ_HIP(szk::launch_compress_stream(d_src, n, d_slots, slot_stride, d_len, flags,
+                                       dual_scratch_for(static_cast<hipStream_t>(stream)),
                                        static_cast<hipStream_t>(stream)));
     return SZ_OK;
 }

@@ -10,12 +10,24 @@ constexpr uint32_t kFlagBlockVarint = 1u;  // == SZ_FLAG_BLOCK_VARINT
 constexpr int32_t kStatusCorrupt = -74;    // == SZ_ECORRUPT
 constexpr int32_t kStatusNoSpace = -28;    // == SZ_ENOSPC
 
+// Workspace of the dual-wave kernel: n_slots generation-tagged tables (16384 x uint32 each) and one
+// generation counter per slot, both zero-initialised once; owned by one stream at a time.
+struct DualScratch {
+    uint32_t *tables;
+    uint32_t *gen;
+    uint32_t n_slots;
+    uint32_t min_blocks;  // launches with fewer blocks use the single kernel
+};
+constexpr size_t kDualTableBytes = 16384 * 4;
+
+// dual == nullptr (or too few blocks): one 64-lane workgroup per block, table in LDS.
 hipError_t launch_compress_blocks(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len,
                                   uint32_t n_blocks, void *d_dst, uint64_t dst_stride,
-                                  uint32_t *d_out_len, uint32_t flags, hipStream_t stream);
+                                  uint32_t *d_out_len, uint32_t flags, const DualScratch *dual,
+                                  hipStream_t stream);
 
 hipError_t launch_compress_stream(const void *d_src, uint64_t n, void *d_slots, uint64_t slot_stride,
-                                  uint32_t *d_len, uint32_t flags, hipStream_t stream);
+                                  uint32_t *d_len, uint32_t flags, const DualScratch *dual, hipStream_t stream);
 
 hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const uint32_t *d_len,
                               uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,

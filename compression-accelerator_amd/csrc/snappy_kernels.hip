@@ -46,11 +46,9 @@ __device__ unsigned long long g_prof[32];
 
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxBlock = 65536u;
-#ifndef SZ_EXPERIMENT_TABLE
-#define SZ_EXPERIMENT_TABLE 16384
-#endif
-static constexpr uint32_t kMaxTable = SZ_EXPERIMENT_TABLE;  // (occupancy experiments shrink it; product: 16384)
+static constexpr uint32_t kMaxTable = 16384u;
 static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
+  // CompressionAccelerator.scala:76-78
 
 // Probe schedule of the scan loop after a (re)start: off[k] = distance of the k-th probe from the
 // first one.  skip_0 = 32, off_{k+1} = off_k + (skip_k >> 5), skip_{k+1} = skip_k + (skip_k >> 5).
@@ -347,49 +345,53 @@ __device__ __forceinline__ uint64_t lanes_below(uint32_t k)  // bits 0..k-1, k i
 // STRIDED BATCH (sc >= 32: the skip heuristic has accelerated).  Lane k takes the k-th future probe
 // of the schedule; the first hit wins and probes behind it are rolled back.
 
-#ifdef SZ_EXPERIMENT_GLOBAL_TABLE
-__device__ uint16_t *g_experiment_tables;
-#endif
-#ifndef SZ_EXPERIMENT_WAVES
-#define SZ_EXPERIMENT_WAVES 1
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMENT_WAVES, SZ_EXPERIMENT_WAVES))) void compress_blocks_kernel(
-    const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
-    uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
-    uint32_t *__restrict__ out_len, uint32_t flags)
-{
-    // The whole LDS budget of this kernel is the table: 32 KiB (4 workgroups resident per CU).
-    // NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
-    // loads/stores with a vmcnt(0) wait after each.  The places that need "really re-read memory"
-    // (other lanes of the same ds_write may have won the bucket) use a compiler barrier.
-#ifdef SZ_EXPERIMENT_GLOBAL_TABLE  // occupancy experiment only: table in global memory, no LDS
-    uint16_t *tab = g_experiment_tables + (size_t)blockIdx.x * kMaxTable;
-#else
-    __shared__ __attribute__((aligned(16))) uint16_t tab[kMaxTable];
-#endif
+// The hash table of one block, in one of two homes:
+//  * LDS, 16384 x uint16, zeroed per block (32 KiB: four of them fit a CU, one per SIMD);
+//  * global memory (L2 / Infinity Cache), 16384 x uint32 entries tagged with a per-slot generation
+//    in the high half so that a new block needs no zeroing pass (an entry of another generation
+//    reads as 0 = empty).  Used by the second wave of a SIMD in the dual kernel, for which no LDS
+//    is left.
+// NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
+// loads/stores with a vmcnt(0) wait after each.  The places that need "really re-read memory"
+// (other lanes of the same store may have won the bucket) use a compiler barrier.
+struct HashTab {
+    uint16_t *lds;
+    uint32_t *glob;
+    uint32_t tag;  // generation << 16
+    bool in_lds;
 
-    const uint32_t lane = threadIdx.x;
-    const uint32_t b = blockIdx.x;
-    if (b >= n_blocks)
-        return;
-    const uint8_t *__restrict__ in = src + (uint64_t)b * in_stride;
-    uint8_t *__restrict__ out = dst + (uint64_t)b * dst_stride;
-    // block length: explicit per block, or the fragments of one contiguous input (ragged tail), or fixed
-    uint32_t n_raw;
-    if (in_len)
-        n_raw = in_len[b];
-    else if (total_len) {
-        const uint64_t left = total_len - (uint64_t)b * in_stride;
-        n_raw = (uint32_t)(left < in_stride ? left : in_stride);
-    } else
-        n_raw = (uint32_t)in_stride;
-    const uint32_t n = uni(n_raw);
-    if (n > kMaxBlock) {  // caller error: flagged, nothing written
-        if (lane == 0)
-            out_len[b] = 0xffffffffu;
-        return;
+    __device__ __forceinline__ uint32_t get(uint32_t h) const
+    {
+        if (in_lds)
+            return lds[h];
+        const uint32_t e = glob[h];
+        return (e & 0xffff0000u) == tag ? (e & 0xffffu) : 0u;
     }
+    __device__ __forceinline__ void put(uint32_t h, uint32_t v) const
+    {
+        if (in_lds)
+            lds[h] = (uint16_t)v;
+        else
+            glob[h] = tag | (v & 0xffffu);
+    }
+    // (a2) table of T = 2^log2T entries, all empty
+    __device__ __forceinline__ void clear(uint32_t log2T, uint32_t lane) const
+    {
+        if (in_lds) {
+            const uint32_t nvec = (1u << log2T) >> 3;  // 16-byte chunks
+            u32x4 z = {0, 0, 0, 0};
+            for (uint32_t i = lane; i < nvec; i += 64)
+                reinterpret_cast<u32x4 *>(lds)[i] = z;
+        }
+    }
+};
 
+// One block by one wavefront.  kChunks = 1 KiB chunks of the block kept in registers.
+template <int kBlkChunks>
+__device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const uint8_t *__restrict__ in,
+                                                       uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
+                                                       uint32_t lane)
+{
     uint32_t op = 0;
     if (flags & kFlagBlockVarint) {  // (a8) varint32(n), n <= 65536 -> at most 3 bytes
         const uint32_t nb = n < 128 ? 1 : (n < 16384 ? 2 : 3);
@@ -397,11 +399,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
             out[lane] = (uint8_t)(((n >> (7 * lane)) & 0x7f) | (lane + 1 < nb ? 0x80 : 0));
         op = nb;
     }
-    if (n == 0) {
-        if (lane == 0)
-            out_len[b] = op;
-        return;
-    }
+    if (n == 0)
+        return op;
 
     uint32_t next_emit = 0;
     if (n >= kInputMargin) {
@@ -436,18 +435,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
         // does when the data is incompressible), that literal is stored straight from these
         // registers.  Chunk c = 64*u + lane holds literal bytes [bhead + 16c, +16), laid out so that
         // the stores are 16-byte aligned for the predicted position of the literal (3-byte tag).
-#ifdef SZ_EXPERIMENT_NO_BLK
-        const bool use_blk = false;
-#else
         const bool use_blk = n >= 16384;
-#endif
         const uint32_t bhead = (16u - (uint32_t)((uintptr_t)(out + op + 3) & 15u)) & 15u;
-        const uint32_t nchunk = use_blk ? (n - bhead) >> 10 : 0;  // whole 1 KiB chunks (wave-uniform)
-        u32x4 blk[64];
+        uint32_t nchunk = use_blk ? (n - bhead) >> 10 : 0;  // whole 1 KiB chunks (wave-uniform)
+        nchunk = nchunk < (uint32_t)kBlkChunks ? nchunk : (uint32_t)kBlkChunks;
+        u32x4 blk[kBlkChunks];
         {
             const uint8_t *bp = in + bhead + 16u * lane;
 #pragma unroll
-            for (int u = 0; u < 64; u++) {
+            for (int u = 0; u < kBlkChunks; u++) {
                 blk[u] = u32x4{0, 0, 0, 0};
                 if ((uint32_t)u < nchunk)
                     blk[u] = ld128_nt(bp + 1024 * u);
@@ -466,12 +462,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
         while (log2T < 14 && (1u << log2T) < n)
             log2T++;
         const uint32_t shift = 32 - log2T;
-        {
-            const uint32_t nvec = (1u << log2T) >> 3;  // 16-byte chunks
-            u32x4 z = {0, 0, 0, 0};
-            for (uint32_t i = lane; i < nvec; i += 64)
-                reinterpret_cast<u32x4 *>(tab)[i] = z;
-        }
+        tab.clear(log2T, lane);
 
         // literal emission; a long block-prefix literal is only accounted for here and stored from
         // the prefetched registers after the main loop (one copy of that code, at a known address)
@@ -509,11 +500,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
                 const uint32_t h = (a.x * kHashMul) >> shift;  // a, a2: loaded by load_window(W0)
                 PROF_LAP(0);
                 if (chain && lane == 0)
-                    tab[h] = (uint16_t)pos;  // the reference inserts P-1 before it looks P up
+                    tab.put(h, pos);  // the reference inserts P-1 before it looks P up
                 const bool spec = valid && lane >= first;
                 uint32_t cand = 0;
                 if (spec)
-                    cand = tab[h];  // table as of the start of the window
+                    cand = tab.get(h);  // table as of the start of the window
                 const uint32_t nvalid = ip_limit - W0 < 64 ? ip_limit - W0 : 64;  // W0 < ip_limit
                 PROF_LAP(1);
                 // candidates' bytes: unpredicated (cand < pos <= n-16, or 0 for lanes without one)
@@ -645,9 +636,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
                     const bool ins_lane = ((V | Ins) >> lane) & 1;
                     uint32_t w = pos & 0xffffu;
                     if (ins_lane) {
-                        tab[h] = (uint16_t)pos;
+                        tab.put(h, pos);
                         asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
-                        w = tab[h];
+                        w = tab.get(h);
                     }
                     uint64_t L = __ballot(ins_lane && w != (pos & 0xffffu));
                     if (L == 0)
@@ -656,7 +647,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
                     // keep the lanes before the second user; the redo cannot conflict again
                     asm volatile("" ::: "memory");
                     if (ins_lane)
-                        tab[h] = (uint16_t)cand;
+                        tab.put(h, cand);
                     uint32_t cut = 64;
                     while (L) {
                         const uint32_t hv = lane_get(h, ctz64(L));
@@ -773,10 +764,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
             uint32_t h = 0, cand = 0, w = p & 0xffffu;
             if (valid) {
                 h = (v * kHashMul) >> shift;
-                cand = tab[h];
-                tab[h] = (uint16_t)p;
+                cand = tab.get(h);
+                tab.put(h, p);
                 asm volatile("" ::: "memory");  // the read-back below must come from LDS, not from p
-                w = tab[h];
+                w = tab.get(h);
             }
             const uint32_t nvalid = (uint32_t)__builtin_popcountll(__ballot(valid));  // valid is a prefix
             const uint64_t losers = __ballot(valid && w != (p & 0xffffu));
@@ -785,7 +776,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
                 // Two lanes of this batch share a bucket: serial order says the later one must see the
                 // earlier one's position.  Roll everything back, keep the longest collision-free prefix.
                 if (valid)
-                    tab[h] = (uint16_t)cand;
+                    tab.put(h, cand);
                 uint64_t L = losers;
                 while (L) {
                     const uint32_t hv = lane_get(h, ctz64(L));
@@ -796,7 +787,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
                     cut = second < cut ? second : cut;
                 }
                 if (valid && lane < cut)
-                    tab[h] = (uint16_t)p;
+                    tab.put(h, p);
             }
             const uint32_t nact = nvalid < cut ? nvalid : cut;
             const bool act = lane < nact;
@@ -813,7 +804,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
             }
             const uint32_t f = ctz64(hits);
             if (act && lane > f)
-                tab[h] = (uint16_t)cand;  // probes behind the first hit never happened
+                tab.put(h, cand);  // probes behind the first hit never happened
             const uint32_t ip = lane_get(p, f);
             const uint32_t cnd = lane_get(cand, f);
             uint32_t m;
@@ -851,7 +842,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
             nreg = nreg < nchunk ? nreg : nchunk;
             uint8_t *dl = d + bhead + 16u * lane;
 #pragma unroll
-            for (int u = 0; u < 64; u++) {
+            for (int u = 0; u < kBlkChunks; u++) {
                 if ((uint32_t)u < nreg)
                     __builtin_nontemporal_store(blk[u], reinterpret_cast<u32x4 *>(dl + 1024 * u));
             }
@@ -862,8 +853,95 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SZ_EXPERIMEN
     }
     if (next_emit < n)  // blocks shorter than the 15-byte margin are one literal
         op = emit_literal(out, op, in + next_emit, n - next_emit, lane);
+    return op;
+}
+
+// block length: explicit per block, or the fragments of one contiguous input (ragged tail), or fixed
+__device__ __forceinline__ uint32_t block_length(const uint32_t *__restrict__ in_len, uint64_t total_len,
+                                                 uint64_t in_stride, uint32_t b)
+{
+    uint32_t n_raw;
+    if (in_len)
+        n_raw = in_len[b];
+    else if (total_len) {
+        const uint64_t left = total_len - (uint64_t)b * in_stride;
+        n_raw = (uint32_t)(left < in_stride ? left : in_stride);
+    } else
+        n_raw = (uint32_t)in_stride;
+    return uni(n_raw);
+}
+
+// Single kernel: one 64-lane workgroup per block, table in LDS, whole block in registers.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void compress_blocks_kernel(
+    const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
+    uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
+    uint32_t *__restrict__ out_len, uint32_t flags)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];  // the whole LDS budget: 32 KiB
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks)
+        return;
+    const uint32_t n = block_length(in_len, total_len, in_stride, b);
+    if (n > kMaxBlock) {  // caller error: flagged, nothing written
+        if (lane == 0)
+            out_len[b] = 0xffffffffu;
+        return;
+    }
+    const HashTab tab{lds_tab, nullptr, 0u, true};
+    const uint32_t op = compress_one_block<64>(tab, src + (uint64_t)b * in_stride, n,
+                                               dst + (uint64_t)b * dst_stride, flags, lane);
     if (lane == 0)
         out_len[b] = op;  // (a9)
+}
+
+// Dual kernel: 128-thread workgroups = two independent wavefronts, each compressing its own blocks.
+// Wave 0 keeps its table in LDS, wave 1 in a generation-tagged table in global memory (slot =
+// blockIdx.x of `scratch`), so that every SIMD hosts two waves and their instruction latencies
+// overlap (a lone wave issues ~1 instruction per 10 cycles).  Persistent grid: workgroup g takes
+// block pairs g, g + gridDim.x, ...  The register budget per wave halves (256), so only the first
+// 24 KiB of a block are kept in registers.
+static constexpr int kDualChunks = 24;
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void compress_blocks_dual_kernel(
+    const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
+    uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
+    uint32_t *__restrict__ out_len, uint32_t flags, uint32_t *__restrict__ scratch_tables,
+    uint32_t *__restrict__ scratch_gen)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *my_glob = scratch_tables + (size_t)blockIdx.x * kMaxTable;
+    uint32_t gen = 0;
+    if (wave == 1)
+        gen = uni(scratch_gen[blockIdx.x]);
+    for (uint32_t pair = blockIdx.x; 2 * (uint64_t)pair < n_blocks; pair += gridDim.x) {
+        const uint32_t b = 2 * pair + wave;
+        if (b >= n_blocks)
+            break;
+        const uint32_t n = block_length(in_len, total_len, in_stride, b);
+        if (n > kMaxBlock) {
+            if (lane == 0)
+                out_len[b] = 0xffffffffu;
+            continue;
+        }
+        HashTab tab{lds_tab, my_glob, 0u, wave == 0};
+        if (wave == 1) {
+            gen = (gen + 1) & 0xffffu;
+            if (gen == 0) {  // generation wrapped: start over from an all-zero table
+                for (uint32_t i = lane; i < kMaxTable; i += 64)
+                    my_glob[i] = 0;
+                gen = 1;
+            }
+            tab.tag = gen << 16;
+        }
+        const uint32_t op = compress_one_block<kDualChunks>(tab, src + (uint64_t)b * in_stride, n,
+                                                            dst + (uint64_t)b * dst_stride, flags, lane);
+        if (lane == 0)
+            out_len[b] = op;
+    }
+    if (wave == 1 && lane == 0)
+        scratch_gen[blockIdx.x] = gen;
 }
 
 // ---------------------------------------------------------------------- stream packing (8f-2)
@@ -1037,7 +1115,46 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
 
 // ------------------------------------------------------------------------------ launchers
 
+static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len, uint64_t total_len,
+                             uint32_t n_blocks, void *d_dst, uint64_t dst_stride, uint32_t *d_out_len,
+                             uint32_t flags, const DualScratch *dual, hipStream_t stream)
+{
+    if (dual && dual->tables && n_blocks >= dual->min_blocks) {
+        // enough blocks to keep two waves per SIMD busy on every CU: persistent dual-wave grid
+        uint32_t grid = (n_blocks + 1) / 2;
+        grid = grid < dual->n_slots ? grid : dual->n_slots;
+        hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(128), 0, stream,
+                           static_cast<const uint8_t *>(d_src), in_stride, d_in_len, total_len, n_blocks,
+                           static_cast<uint8_t *>(d_dst), dst_stride, d_out_len, flags, dual->tables, dual->gen);
+    } else {
+        hipLaunchKernelGGL(compress_blocks_kernel, dim3(n_blocks), dim3(64), 0, stream,
+                           static_cast<const uint8_t *>(d_src), in_stride, d_in_len, total_len, n_blocks,
+                           static_cast<uint8_t *>(d_dst), dst_stride, d_out_len, flags);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_compress_blocks(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len,
+                                  uint32_t n_blocks, void *d_dst, uint64_t dst_stride,
+                                  uint32_t *d_out_len, uint32_t flags, const DualScratch *dual,
+                                  hipStream_t stream)
+{
+    if (n_blocks == 0)
+        return hipSuccess;
+    return launch_any(d_src, in_stride, d_in_len, 0, n_blocks, d_dst, dst_stride, d_out_len, flags, dual, stream);
+}
+
+hipError_t launch_compress_stream(const void *d_src, uint64_t n, void *d_slots, uint64_t slot_stride,
+                                  uint32_t *d_len, uint32_t flags, const DualScratch *dual, hipStream_t stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    const uint32_t n_blocks = (uint32_t)((n + kMaxBlock - 1) / kMaxBlock);
+    return launch_any(d_src, kMaxBlock, nullptr, n, n_blocks, d_slots, slot_stride, d_len, flags, dual, stream);
+}
+
+#if 0
+hipError_t launch_compress_blocks_old(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len,
                                   uint32_t n_blocks, void *d_dst, uint64_t dst_stride,
                                   uint32_t *d_out_len, uint32_t flags, hipStream_t stream)
 {
@@ -1061,6 +1178,8 @@ hipError_t launch_compress_stream(const void *d_src, uint64_t n, void *d_slots, 
                        static_cast<uint8_t *>(d_slots), slot_stride, d_len, flags);
     return hipGetLastError();
 }
+
+#endif
 
 hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const uint32_t *d_len,
                               uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
