@@ -898,9 +898,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // Dual kernel: 128-thread workgroups = two independent wavefronts, each compressing its own blocks.
 // Wave 0 keeps its table in LDS, wave 1 in a generation-tagged table in global memory (slot =
 // blockIdx.x of `scratch`), so that every SIMD hosts two waves and their instruction latencies
-// overlap (a lone wave issues ~1 instruction per 10 cycles).  Persistent grid: workgroup g takes
-// block pairs g, g + gridDim.x, ...  The register budget per wave halves (256), so only the first
-// 24 KiB of a block are kept in registers.
+// overlap (a lone wave issues ~1 instruction per 10 cycles).  Persistent grid: every workgroup owns
+// a contiguous share of the blocks and its two waves pull block indices from a counter in LDS, so
+// the faster (LDS-table) wave takes more of them.  The register budget per wave halves (256), so
+// only the first 24 KiB of a block are kept in registers.
 static constexpr int kDualChunks = 24;
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void compress_blocks_dual_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
@@ -909,15 +910,26 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     uint32_t *__restrict__ scratch_gen)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
+    __shared__ uint32_t next_block;  // work queue of this workgroup: its two waves pull from it
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
+    // contiguous share of the blocks for this workgroup
+    const uint32_t per = (n_blocks + gridDim.x - 1) / gridDim.x;
+    const uint32_t b_begin = blockIdx.x * per < n_blocks ? blockIdx.x * per : n_blocks;
+    const uint32_t b_end = b_begin + per < n_blocks ? b_begin + per : n_blocks;
+    if (threadIdx.x == 0)
+        next_block = b_begin;
+    __syncthreads();  // the only barrier: from here on the two waves run independently
     uint32_t *my_glob = scratch_tables + (size_t)blockIdx.x * kMaxTable;
     uint32_t gen = 0;
     if (wave == 1)
         gen = uni(scratch_gen[blockIdx.x]);
-    for (uint32_t pair = blockIdx.x; 2 * (uint64_t)pair < n_blocks; pair += gridDim.x) {
-        const uint32_t b = 2 * pair + wave;
-        if (b >= n_blocks)
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0)
+            b = atomicAdd(&next_block, 1u);  // LDS atomic: the faster wave simply takes more blocks
+        b = uni(b);
+        if (b >= b_end)
             break;
         const uint32_t n = block_length(in_len, total_len, in_stride, b);
         if (n > kMaxBlock) {
