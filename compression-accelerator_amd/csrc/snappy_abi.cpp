@@ -27,8 +27,8 @@ std::map<std::pair<int, hipStream_t>, szk::DualScratch> g_dual;
 
 const szk::DualScratch *dual_scratch_for(hipStream_t stream)
 {
-    // SZ_KERNEL=single: never; SZ_KERNEL=dual: whenever there are at least two blocks (tests);
-    // default: when there are enough blocks to give every SIMD two waves.
+    // SZ_KERNEL=single: never; SZ_KERNEL=dual: always, from two blocks up (tests); default (auto):
+    // when there are enough blocks to give every SIMD two waves, a sample of the data decides.
     static const int mode = [] {
         const char *e = getenv("SZ_KERNEL");
         return !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : 0;
@@ -43,7 +43,7 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
     auto it = g_dual.find(key);
     if (it != g_dual.end())
         return it->second.tables ? &it->second : nullptr;
-    szk::DualScratch sc{nullptr, nullptr, 0, 0};
+    szk::DualScratch sc{nullptr, nullptr, nullptr, 0, 0, mode == 2 ? szk::kDualAlways : szk::kDualAuto};
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
@@ -54,12 +54,14 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
         sc.n_slots = 4u * (uint32_t)cus;  // four 128-thread workgroups per CU = two waves per SIMD
         sc.min_blocks = mode == 2 ? 2u : 2u * sc.n_slots;
         void *t = nullptr, *g = nullptr;
+        const size_t gbytes = ((size_t)sc.n_slots + 2) * sizeof(uint32_t);  // generations + [repeats, positions]
         if (hipMalloc(&t, (size_t)sc.n_slots * szk::kDualTableBytes) == hipSuccess &&
-            hipMalloc(&g, (size_t)sc.n_slots * sizeof(uint32_t)) == hipSuccess &&
+            hipMalloc(&g, gbytes) == hipSuccess &&
             hipMemsetAsync(t, 0, (size_t)sc.n_slots * szk::kDualTableBytes, stream) == hipSuccess &&
-            hipMemsetAsync(g, 0, (size_t)sc.n_slots * sizeof(uint32_t), stream) == hipSuccess) {
+            hipMemsetAsync(g, 0, gbytes, stream) == hipSuccess) {
             sc.tables = static_cast<uint32_t *>(t);
             sc.gen = static_cast<uint32_t *>(g);
+            sc.select = sc.gen + sc.n_slots;
         } else {
             (void)hipGetLastError();
             if (t) (void)hipFree(t);

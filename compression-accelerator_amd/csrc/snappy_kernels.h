@@ -12,11 +12,14 @@ constexpr int32_t kStatusNoSpace = -28;    // == SZ_ENOSPC
 
 // Workspace of the dual-wave kernel: n_slots generation-tagged tables (16384 x uint32 each) and one
 // generation counter per slot, both zero-initialised once; owned by one stream at a time.
+enum DualMode : uint32_t { kDualAuto = 0, kDualAlways = 2 };
 struct DualScratch {
     uint32_t *tables;
     uint32_t *gen;
+    uint32_t *select;     // [repeats, positions] of the compressibility sample (auto mode)
     uint32_t n_slots;
     uint32_t min_blocks;  // launches with fewer blocks use the single kernel
+    uint32_t mode;        // kDualAuto: pick single/dual per launch from a data sample
 };
 constexpr size_t kDualTableBytes = 16384 * 4;
 

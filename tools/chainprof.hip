@@ -15,7 +15,7 @@ int main(int argc, char** argv){
   for(int rep=0;rep<2;rep++){
     unsigned long long z[32]={0}; hipMemcpyToSymbol(HIP_SYMBOL(szk::g_prof), z, sizeof z);
     hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0);
-    szk::launch_compress_blocks(d_in,65536,nullptr,nb,d_out,76544,d_len,1,0);
+    szk::launch_compress_blocks(d_in,65536,nullptr,nb,d_out,76544,d_len,1,nullptr,0);
     hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1);
     unsigned long long p[32]; hipMemcpyFromSymbol(p, HIP_SYMBOL(szk::g_prof), sizeof p);
     if(rep==1){ printf("nb=%u kernel %.3f ms\n", nb, ms); unsigned long long tot=0; for(int i=0;i<16;i++) tot+=p[i];
