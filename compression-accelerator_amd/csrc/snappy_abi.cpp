@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include "snappy_kernels.h"
 
@@ -29,10 +30,10 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
 {
     // SZ_KERNEL=single: never; SZ_KERNEL=dual: always, from two blocks up (tests); default (auto):
     // when there are enough blocks to give every SIMD two waves, a sample of the data decides.
-    static const int mode = [] {
-        const char *e = getenv("SZ_KERNEL");
-        return !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : 0;
-    }();
+    // Read on every call so that a test can switch modes inside one process.
+    const char *e = getenv("SZ_KERNEL");
+    const int mode = !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : 0;
+    thread_local szk::DualScratch view;
     if (mode == 1)
         return nullptr;
     int dev = 0;
@@ -40,9 +41,17 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
         return nullptr;
     std::lock_guard<std::mutex> lock(g_dual_mutex);
     auto key = std::make_pair(dev, stream);
+    auto finish = [&](const szk::DualScratch &sc) -> const szk::DualScratch * {
+        if (!sc.tables)
+            return nullptr;
+        view = sc;
+        view.mode = mode == 2 ? szk::kDualAlways : szk::kDualAuto;
+        view.min_blocks = mode == 2 ? 2u : 2u * sc.n_slots;
+        return &view;
+    };
     auto it = g_dual.find(key);
     if (it != g_dual.end())
-        return it->second.tables ? &it->second : nullptr;
+        return finish(it->second);
     szk::DualScratch sc{nullptr, nullptr, nullptr, 0, 0, mode == 2 ? szk::kDualAlways : szk::kDualAuto};
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
@@ -52,7 +61,6 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
         sc.n_slots = 4u * (uint32_t)cus;  // four 128-thread workgroups per CU = two waves per SIMD
-        sc.min_blocks = mode == 2 ? 2u : 2u * sc.n_slots;
         void *t = nullptr, *g = nullptr;
         const size_t gbytes = ((size_t)sc.n_slots + 2) * sizeof(uint32_t);  // generations + [repeats, positions]
         if (hipMalloc(&t, (size_t)sc.n_slots * szk::kDualTableBytes) == hipSuccess &&
@@ -62,15 +70,18 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
             sc.tables = static_cast<uint32_t *>(t);
             sc.gen = static_cast<uint32_t *>(g);
             sc.select = sc.gen + sc.n_slots;
+            if (const char *gi = getenv("SZ_TEST_GEN_INIT")) {  // test hook: start near the 16-bit wrap
+                std::vector<uint32_t> init(sc.n_slots, (uint32_t)strtoul(gi, nullptr, 0) & 0xffffu);
+                (void)hipMemcpy(g, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            }
         } else {
             (void)hipGetLastError();
             if (t) (void)hipFree(t);
             if (g) (void)hipFree(g);
         }
     }
-    auto &slot = g_dual[key];
-    slot = sc;
-    return slot.tables ? &slot : nullptr;
+    g_dual[key] = sc;
+    return finish(sc);
 }
 
 thread_local int tl_hip_error = 0;

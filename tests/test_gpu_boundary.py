@@ -192,6 +192,50 @@ def _full_size_round_trip(kind, n_blocks, expect_len=None):
     return lens
 
 
+@pytest.mark.parametrize("mode", ["single", "dual"])
+def test_full_size_forced_kernels(mode, monkeypatch):
+    """The two compress kernels at full size on every workload (auto mode picks one per launch)."""
+    monkeypatch.setenv("SZ_KERNEL", mode)
+    _full_size_round_trip("c3", 4096, expect_len=65542)
+    _full_size_round_trip("text", 2048)
+    _full_size_round_trip("mix", 3072)
+
+
+def test_generation_tags_survive_many_launches(monkeypatch):
+    """The dual kernel's global tables are never zeroed between blocks: entries carry a 16-bit
+    generation.  Push one slot through several hundred generations and check parity each time."""
+    import torch
+    monkeypatch.setenv("SZ_KERNEL", "dual")
+    P = pkg()
+    blocks = [fuzzgen.gen("text_mtg", 31337 + i, 65536).tobytes() for i in range(2)]
+    want = [oracle_lib.raw_compress(b) for b in blocks]
+    for it in range(300):
+        got = compress_many(blocks)
+        assert got == want, it
+
+
+def test_generation_wrap_rezeroes_the_table(monkeypatch):
+    """Generation 65535 -> 0 wraps: the slot's table is zeroed and generation 1 starts over.  A fresh
+    stream gets a fresh workspace, seeded just below the wrap through the SZ_TEST_GEN_INIT hook."""
+    import torch
+    monkeypatch.setenv("SZ_KERNEL", "dual")
+    monkeypatch.setenv("SZ_TEST_GEN_INIT", "65530")
+    P = pkg()
+    blocks = [fuzzgen.gen("words", 4242 + i, 65536).tobytes() for i in range(4)]
+    want = [oracle_lib.raw_compress(b) for b in blocks]
+    host = np.stack([np.frombuffer(b, dtype=np.uint8) for b in blocks])
+    src = torch.from_numpy(host).cuda().reshape(-1)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for it in range(24):  # crosses 65535 -> 0 on every slot that wave 1 uses
+            dst, out_len = P.compress_blocks(src, 65536, 4, stream=st)
+            st.synchronize()
+            ol = out_len.cpu().numpy()
+            out = dst.cpu().numpy().reshape(4, P.SLOT_STRIDE)
+            for i in range(4):
+                assert out[i, :ol[i]].tobytes() == want[i], (it, i)
+
+
 def test_full_size_c3_one_gib_tiled_random_ascii():
     # BASELINE.json configs[2]: every 64 KiB window of the tiling is incompressible -> one literal,
     # 3 (varint) + 3 (tag) + 65536 bytes (SURVEY.md App. B)
