@@ -213,6 +213,7 @@ def main():
                                     "c5": "C5 4 KiB text pattern x16", "mix": "C4 mix c3/text/c5"}[args.workload]
                        + ", %d x 64 KiB blocks per GPU (%.2f GiB/GPU)" % (B, B * BLOCK / 2**30),
                        "blocks_per_gpu": B, "block_bytes": BLOCK,
+                       "kernel": os.environ.get("SZ_KERNEL", "auto (sampled: single for incompressible, dual otherwise)"),
                        "sharding": "contiguous block ranges, no data-path collective; all_gather of uint32 lengths over RCCL"},
             "compressed_size_ratio_vs_ref": 1.0 if exact_all else None,
             "bit_exact_vs_oracle_sample": exact_all,

@@ -62,7 +62,7 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
         sc.n_slots = 4u * (uint32_t)cus;  // four 128-thread workgroups per CU = two waves per SIMD
         void *t = nullptr, *g = nullptr;
-        const size_t gbytes = ((size_t)sc.n_slots + 2) * sizeof(uint32_t);  // generations + [repeats, positions]
+        const size_t gbytes = ((size_t)sc.n_slots + 4) * sizeof(uint32_t);  // generations + [repeats, positions, next block]
         if (hipMalloc(&t, (size_t)sc.n_slots * szk::kDualTableBytes) == hipSuccess &&
             hipMalloc(&g, gbytes) == hipSuccess &&
             hipMemsetAsync(t, 0, (size_t)sc.n_slots * szk::kDualTableBytes, stream) == hipSuccess &&

@@ -16,7 +16,7 @@ enum DualMode : uint32_t { kDualAuto = 0, kDualAlways = 2 };
 struct DualScratch {
     uint32_t *tables;
     uint32_t *gen;
-    uint32_t *select;     // [repeats, positions] of the compressibility sample (auto mode)
+    uint32_t *select;     // [repeats, positions] of the compressibility sample + [next block] of the queue
     uint32_t n_slots;
     uint32_t min_blocks;  // launches with fewer blocks use the single kernel
     uint32_t mode;        // kDualAuto: pick single/dual per launch from a data sample

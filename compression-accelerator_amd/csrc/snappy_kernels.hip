@@ -874,7 +874,7 @@ __device__ __forceinline__ uint32_t block_length(const uint32_t *__restrict__ in
 // ---- kernel selection by sampled compressibility (auto mode)
 // The dual kernel wins on compressible data (two waves per SIMD hide each other's instruction
 // latency: text +30%, low-entropy +37%), the single kernel on incompressible data (whole block in
-// registers, no slow global-table wave: +7%).  A tiny sampling kernel looks at the first 4 KiB of up
+// registers, no slow global-table wave: +7%).  A tiny sampling kernel looks at the first 1 KiB of up
 // to 64 evenly spaced blocks and counts 4-byte shingles seen before (16-bit hash into an LDS
 // bitmap); both kernels are launched and the one not chosen exits at once.  Either kernel produces
 // the same bytes, so a wrong guess only costs speed.
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(256) void sample_compressibility_kernel(
     __syncthreads();
     const uint32_t b = (uint32_t)(((uint64_t)blockIdx.x * n_blocks) / gridDim.x);
     uint32_t n = block_length(in_len, total_len, in_stride, b);
-    n = n > kMaxBlock ? 0 : (n < 4096 ? n : 4096);
+    n = n > kMaxBlock ? 0 : (n < 1024 ? n : 1024);  // text repeats >= 23 % of its shingles within 1 KiB
     const uint8_t *in = src + (uint64_t)b * in_stride;
     const uint32_t npos = n >= 4 ? n - 3 : 0;
     uint32_t dups = 0;
@@ -943,30 +943,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // Dual kernel: 128-thread workgroups = two independent wavefronts, each compressing its own blocks.
 // Wave 0 keeps its table in LDS, wave 1 in a generation-tagged table in global memory (slot =
 // blockIdx.x of `scratch`), so that every SIMD hosts two waves and their instruction latencies
-// overlap (a lone wave issues ~1 instruction per 10 cycles).  Persistent grid: every workgroup owns
-// a contiguous share of the blocks and its two waves pull block indices from a counter in LDS, so
-// the faster (LDS-table) wave takes more of them.  The register budget per wave halves (256), so
+// overlap (a lone wave issues ~1 instruction per 10 cycles).  Persistent grid: all waves pull block
+// indices from one device-wide counter (zeroed by a memset node ahead of the launch), so the
+// faster (LDS-table) waves take more of them and mixed workloads balance.  The register budget per wave halves (256), so
 // only the first 24 KiB of a block are kept in registers.
 static constexpr int kDualChunks = 24;
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void compress_blocks_dual_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
     uint32_t *__restrict__ out_len, uint32_t flags, uint32_t *__restrict__ scratch_tables,
-    uint32_t *__restrict__ scratch_gen, const uint32_t *__restrict__ select)
+    uint32_t *__restrict__ scratch_gen, uint32_t *__restrict__ select, uint32_t auto_mode)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
-    __shared__ uint32_t next_block;
-    if (select && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
-        return;  // work queue of this workgroup: its two waves pull from it
+    if (auto_mode && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
+        return;
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    // contiguous share of the blocks for this workgroup
-    const uint32_t per = (n_blocks + gridDim.x - 1) / gridDim.x;
-    const uint32_t b_begin = blockIdx.x * per < n_blocks ? blockIdx.x * per : n_blocks;
-    const uint32_t b_end = b_begin + per < n_blocks ? b_begin + per : n_blocks;
-    if (threadIdx.x == 0)
-        next_block = b_begin;
-    __syncthreads();  // the only barrier: from here on the two waves run independently
     uint32_t *my_glob = scratch_tables + (size_t)blockIdx.x * kMaxTable;
     uint32_t gen = 0;
     if (wave == 1)
@@ -974,9 +966,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (;;) {
         uint32_t b = 0;
         if (lane == 0)
-            b = atomicAdd(&next_block, 1u);  // LDS atomic: the faster wave simply takes more blocks
+            b = atomicAdd(&select[2], 1u);  // one queue for the whole grid: faster waves take more blocks
         b = uni(b);
-        if (b >= b_end)
+        if (b >= n_blocks)
             break;
         const uint32_t n = block_length(in_len, total_len, in_stride, b);
         if (n > kMaxBlock) {
@@ -1182,11 +1174,13 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
     uint8_t *dst = static_cast<uint8_t *>(d_dst);
     const bool dual_ok = dual && dual->tables && n_blocks >= dual->min_blocks;
     const uint32_t *select = nullptr;
-    if (dual_ok && dual->mode == kDualAuto) {
-        // sample -> both kernels, each checks the verdict first (graph-capture safe: no host sync)
-        hipError_t e = hipMemsetAsync(dual->select, 0, 2 * sizeof(uint32_t), stream);
+    if (dual_ok) {  // [repeats, positions, next block] of this launch
+        hipError_t e = hipMemsetAsync(dual->select, 0, 3 * sizeof(uint32_t), stream);
         if (e != hipSuccess)
             return e;
+    }
+    if (dual_ok && dual->mode == kDualAuto) {
+        // sample -> both kernels, each checks the verdict first (graph-capture safe: no host sync)
         const uint32_t ns = n_blocks < 64 ? n_blocks : 64;
         hipLaunchKernelGGL(sample_compressibility_kernel, dim3(ns), dim3(256), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dual->select);
@@ -1201,7 +1195,7 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
         grid = grid < dual->n_slots ? grid : dual->n_slots;
         hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(128), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->tables,
-                           dual->gen, select);
+                           dual->gen, dual->select, dual->mode == kDualAuto ? 1u : 0u);
     }
     return hipGetLastError();
 }
