@@ -212,3 +212,46 @@ def test_oracle_rejects_malformed_streams():
     for bad in (good[:-1], good[:3], b"\xff\xff\xff\xff\xff\xff", good[:1] + b"\x05\x00\x10"):
         with pytest.raises(ValueError):
             oracle_lib.uncompress(bad)
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """SURVEY section 5 (sanitizers): GPU ASan is not available on this pool, so the sanitizer run is
+    on the CPU side -- the oracle built with -fsanitize=address,undefined, driven over edge sizes
+    and every generator in a child process (the sanitizer runtime has to be preloaded)."""
+    import subprocess
+    import sys
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.exists(asan):
+        pytest.skip("libasan not available")
+    subprocess.check_call(["make", "-s", "-C", oracle_lib.ORACLE_DIR, "liboracle_snappy_asan.so"])
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+import numpy as np, fuzzgen
+L = ctypes.CDLL(%r)
+L.oracle_raw_compress.restype = ctypes.c_size_t
+L.oracle_raw_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+L.oracle_uncompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+seed = 1
+for kind in fuzzgen.KINDS:
+    for n in (0, 1, 14, 15, 16, 17, 63, 64, 65, 4096, 65535, 65536, 65537, 140000):
+        a = np.ascontiguousarray(fuzzgen.gen(kind, seed, n)); seed += 1
+        src = np.empty(max(n, 1), dtype=np.uint8); src[:n] = a      # exact-size buffers: any overrun trips ASan
+        cap = 32 + n + n // 6
+        out = np.empty(cap, dtype=np.uint8)
+        k = L.oracle_raw_compress(src.ctypes.data, n, out.ctypes.data)
+        assert k <= cap
+        comp = np.ascontiguousarray(out[:k]).copy()
+        back = np.empty(max(n, 1), dtype=np.uint8); m = ctypes.c_size_t(0)
+        assert L.oracle_uncompress(comp.ctypes.data, k, back.ctypes.data, n, ctypes.byref(m)) == 0 and m.value == n
+        assert (back[:n] == a).all()
+        # truncated / corrupted streams must be rejected without touching memory out of bounds
+        for cut in (1, k // 2, k - 1):
+            if 0 < cut < k:
+                t = comp[:cut].copy()
+                L.oracle_uncompress(t.ctypes.data, cut, back.ctypes.data, n, ctypes.byref(m))
+print("sanitizer run ok")
+''' % (os.path.dirname(os.path.abspath(__file__)), os.path.join(oracle_lib.ORACLE_DIR, "liboracle_snappy_asan.so"))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "sanitizer run ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
