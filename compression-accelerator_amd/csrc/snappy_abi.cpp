@@ -21,8 +21,8 @@
 
 namespace {
 
-// Dual-wave kernel workspace: one per (device, stream), created on first use and kept for the life
-// of the process (64 MiB on MI355X).  SZ_KERNEL=single disables the dual kernel.
+// Multi-wave kernel workspace: one per (device, stream), created on first use and kept for the life
+// of the process (128 MiB on MI355X: 2 048 tagged tables).  SZ_KERNEL=single disables the dual kernel.
 std::mutex g_dual_mutex;
 std::map<std::pair<int, hipStream_t>, szk::DualScratch> g_dual;
 
@@ -60,18 +60,19 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
     }
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
-        sc.n_slots = 4u * (uint32_t)cus;  // four 128-thread workgroups per CU = two waves per SIMD
+        sc.n_slots = 4u * (uint32_t)cus;  // four workgroups per CU, kGroupWaves waves each
         void *t = nullptr, *g = nullptr;
-        const size_t gbytes = ((size_t)sc.n_slots + 4) * sizeof(uint32_t);  // generations + [repeats, positions, next block]
-        if (hipMalloc(&t, (size_t)sc.n_slots * szk::kDualTableBytes) == hipSuccess &&
+        const size_t gbytes = ((size_t)sc.n_slots * szk::kDualTablesPerGroup + 4) * sizeof(uint32_t);  // generations + [repeats, positions, next block]
+        const size_t tbytes = (size_t)sc.n_slots * szk::kDualTablesPerGroup * szk::kDualTableBytes;
+        if (hipMalloc(&t, tbytes) == hipSuccess &&
             hipMalloc(&g, gbytes) == hipSuccess &&
-            hipMemsetAsync(t, 0, (size_t)sc.n_slots * szk::kDualTableBytes, stream) == hipSuccess &&
+            hipMemsetAsync(t, 0, tbytes, stream) == hipSuccess &&
             hipMemsetAsync(g, 0, gbytes, stream) == hipSuccess) {
             sc.tables = static_cast<uint32_t *>(t);
             sc.gen = static_cast<uint32_t *>(g);
-            sc.select = sc.gen + sc.n_slots;
+            sc.select = sc.gen + (size_t)sc.n_slots * szk::kDualTablesPerGroup;
             if (const char *gi = getenv("SZ_TEST_GEN_INIT")) {  // test hook: start near the 16-bit wrap
-                std::vector<uint32_t> init(sc.n_slots, (uint32_t)strtoul(gi, nullptr, 0) & 0xffffu);
+                std::vector<uint32_t> init((size_t)sc.n_slots * szk::kDualTablesPerGroup, (uint32_t)strtoul(gi, nullptr, 0) & 0xffffu);
                 (void)hipMemcpy(g, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
             }
         } else {

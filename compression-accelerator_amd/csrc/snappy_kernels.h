@@ -22,6 +22,10 @@ struct DualScratch {
     uint32_t mode;        // kDualAuto: pick single/dual per launch from a data sample
 };
 constexpr size_t kDualTableBytes = 16384 * 4;
+#ifndef SZ_GROUP_WAVES
+#define SZ_GROUP_WAVES 3
+#endif
+constexpr uint32_t kDualTablesPerGroup = SZ_GROUP_WAVES - 1;  // global tables per workgroup
 
 // dual == nullptr (or too few blocks): one 64-lane workgroup per block, table in LDS.
 hipError_t launch_compress_blocks(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len,

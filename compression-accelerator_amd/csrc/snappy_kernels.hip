@@ -435,11 +435,11 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
         // does when the data is incompressible), that literal is stored straight from these
         // registers.  Chunk c = 64*u + lane holds literal bytes [bhead + 16c, +16), laid out so that
         // the stores are 16-byte aligned for the predicted position of the literal (3-byte tag).
-        const bool use_blk = n >= 16384;
+        const bool use_blk = kBlkChunks > 0 && n >= 16384;
         const uint32_t bhead = (16u - (uint32_t)((uintptr_t)(out + op + 3) & 15u)) & 15u;
         uint32_t nchunk = use_blk ? (n - bhead) >> 10 : 0;  // whole 1 KiB chunks (wave-uniform)
         nchunk = nchunk < (uint32_t)kBlkChunks ? nchunk : (uint32_t)kBlkChunks;
-        u32x4 blk[kBlkChunks];
+        u32x4 blk[kBlkChunks > 0 ? kBlkChunks : 1];
         {
             const uint8_t *bp = in + bhead + 16u * lane;
 #pragma unroll
@@ -940,15 +940,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         out_len[b] = op;  // (a9)
 }
 
-// Dual kernel: 128-thread workgroups = two independent wavefronts, each compressing its own blocks.
-// Wave 0 keeps its table in LDS, wave 1 in a generation-tagged table in global memory (slot =
-// blockIdx.x of `scratch`), so that every SIMD hosts two waves and their instruction latencies
-// overlap (a lone wave issues ~1 instruction per 10 cycles).  Persistent grid: all waves pull block
-// indices from one device-wide counter (zeroed by a memset node ahead of the launch), so the
-// faster (LDS-table) waves take more of them and mixed workloads balance.  The register budget per wave halves (256), so
-// only the first 24 KiB of a block are kept in registers.
-static constexpr int kDualChunks = 24;
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void compress_blocks_dual_kernel(
+// Multi-wave ("dual") kernel: workgroups of kGroupWaves independent wavefronts, each compressing its
+// own blocks, four workgroups per CU, so that every SIMD hosts kGroupWaves waves and their
+// instruction latencies overlap (a lone wave issues ~1 instruction per 10 cycles).  Wave 0 keeps
+// its table in LDS; the others have generation-tagged tables in global memory (one slot each in
+// `scratch`).  Persistent grid: all waves pull block indices from one device-wide counter (zeroed
+// by a memset node ahead of the launch), so the faster (LDS-table) waves take more of them and
+// mixed workloads balance.  Measured on 64 KiB text blocks: 2 waves 42 GB/s, 3 waves 48, 4 waves 44
+// (register spills); one wave per SIMD (single kernel) 32.  With 3 waves a wave has 170 registers,
+// so no part of the block is kept in registers (incompressible data goes to the single kernel).
+#ifndef SZ_GROUP_WAVES
+#define SZ_GROUP_WAVES 3  // waves per workgroup = waves per SIMD (one LDS-table wave + global-table waves)
+#endif
+static constexpr int kGroupWaves = SZ_GROUP_WAVES;
+static constexpr int kDualChunks = kGroupWaves == 2 ? 24 : 0;
+__global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_eu(kGroupWaves, kGroupWaves))) void compress_blocks_dual_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
     uint32_t *__restrict__ out_len, uint32_t flags, uint32_t *__restrict__ scratch_tables,
@@ -959,10 +965,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t *my_glob = scratch_tables + (size_t)blockIdx.x * kMaxTable;
+    const uint32_t my_slot = blockIdx.x * (kGroupWaves - 1) + (wave ? wave - 1 : 0);
+    uint32_t *my_glob = scratch_tables + (size_t)my_slot * kMaxTable;
     uint32_t gen = 0;
-    if (wave == 1)
-        gen = uni(scratch_gen[blockIdx.x]);
+    if (wave >= 1)
+        gen = uni(scratch_gen[my_slot]);
     for (;;) {
         uint32_t b = 0;
         if (lane == 0)
@@ -977,7 +984,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             continue;
         }
         HashTab tab{lds_tab, my_glob, 0u, wave == 0};
-        if (wave == 1) {
+        if (wave >= 1) {
             gen = (gen + 1) & 0xffffu;
             if (gen == 0) {  // generation wrapped: start over from an all-zero table
                 for (uint32_t i = lane; i < kMaxTable; i += 64)
@@ -991,8 +998,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (lane == 0)
             out_len[b] = op;
     }
-    if (wave == 1 && lane == 0)
-        scratch_gen[blockIdx.x] = gen;
+    if (wave >= 1 && lane == 0)
+        scratch_gen[my_slot] = gen;
 }
 
 // ---------------------------------------------------------------------- stream packing (8f-2)
@@ -1191,9 +1198,9 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
                            total_len, n_blocks, dst, dst_stride, d_out_len, flags, select);
     if (dual_ok) {
         // enough blocks to keep two waves per SIMD busy on every CU: persistent dual-wave grid
-        uint32_t grid = (n_blocks + 1) / 2;
+        uint32_t grid = (n_blocks + kGroupWaves - 1) / kGroupWaves;
         grid = grid < dual->n_slots ? grid : dual->n_slots;
-        hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(128), 0, stream, src, in_stride,
+        hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(64 * kGroupWaves), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->tables,
                            dual->gen, dual->select, dual->mode == kDualAuto ? 1u : 0u);
     }

@@ -27,8 +27,8 @@
  * negative SZ_E* on failure; no exceptions cross this boundary; no CPU fallback -- without a
  * usable GPU every compute entry point returns SZ_ENODEV / SZ_EHIP.
  * Device entry points are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
- * default stream) and never synchronise.  The compress entry points keep a 64 MiB workspace per
- * (device, stream) for the two-waves-per-SIMD kernel; it is allocated by the first call on a stream
+ * default stream) and never synchronise.  The compress entry points keep a 128 MiB workspace per
+ * (device, stream) for the three-waves-per-SIMD kernel; it is allocated by the first call on a stream
  * that is not being captured (a call made during graph capture before that simply uses the
  * one-wave kernel), so make one warm-up call before capturing a graph.  Which kernel runs is
  * chosen per launch from a sample of the data; environment SZ_KERNEL=single|dual forces one
