@@ -175,7 +175,7 @@ def main():
 
     extras = {}
     if not args.no_extra:
-        for kind, nb in (("text", 4096), ("c5", 8192), ("mix", 6144)):
+        for kind, nb in (("text", 16384), ("c5", 16384), ("mix", 16386)):
             if kind == args.workload:
                 continue
             r = run_workload(P, kind, rank * nb, nb, 3, 1, device, dist_on)

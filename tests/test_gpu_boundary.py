@@ -25,7 +25,10 @@ def sha(b):
 
 # ------------------------------------------------------------------ host-buffer API
 
-def test_host_compress_is_snappy_compress():
+@pytest.mark.parametrize("mode", ["auto", "dual"])
+def test_host_compress_is_snappy_compress(mode, monkeypatch):
+    if mode != "auto":
+        monkeypatch.setenv("SZ_KERNEL", mode)  # ragged last fragment through the multi-wave kernel too
     P = pkg()
     mtg = fuzzgen.corpus("mtg")
     cases = [b"", b"a", b"ab" * 7, mtg[:65535], mtg[:65536], mtg[:65537], mtg[:200001],
