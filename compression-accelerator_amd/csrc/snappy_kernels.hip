@@ -403,6 +403,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
         return op;
 
     uint32_t next_emit = 0;
+    bool poisoned = false;
     if (n >= kInputMargin) {
         const uint32_t ip_limit = n - kInputMargin;  // positions <= n-16 may be probed
 
@@ -484,6 +485,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
         PROF_DECL
         PROF_START();
         for (;;) {
+            if (poisoned)
+                break;
 #ifdef SZ_ABLATION
             if (flags & 0x200u)  // timing ablation: no match finding at all (one literal)
                 break;
@@ -656,6 +659,13 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
                         const uint64_t G2 = G & (G - 1);
                         const uint32_t second = ctz64(G2);
                         cut = second < cut ? second : cut;
+                    }
+                    // (a lost write that no shared bucket explains would repeat forever: with an LDS
+                    // table it cannot happen; with a global-memory table it would mean this wave's
+                    // store -> load order was not kept.  Poison the block's result, never hang.)
+                    if (cut >= lim) {
+                        poisoned = true;
+                        break;
                     }
                     lim = cut;
                 }
@@ -853,7 +863,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
     }
     if (next_emit < n)  // blocks shorter than the 15-byte margin are one literal
         op = emit_literal(out, op, in + next_emit, n - next_emit, lane);
-    return op;
+    return poisoned ? 0xfffffffeu : op;
 }
 
 // block length: explicit per block, or the fragments of one contiguous input (ragged tail), or fixed
