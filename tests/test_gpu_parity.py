@@ -133,3 +133,34 @@ def test_bucket_collision_stress():
     got = compress_many(blocks)
     for i, (g, b) in enumerate(zip(got, blocks)):
         _assert_same(g, oracle_lib.raw_compress(b), "collision case %d (n=%d)" % (i, len(b)))
+
+
+def test_unaligned_buffers_and_odd_strides():
+    """Nothing in the ABI promises alignment: source and destination at odd addresses, strides that
+    are not multiples of anything, explicit per-block lengths including empty blocks."""
+    import torch
+    P = pkg()
+    rs = np.random.RandomState(5)
+    for (src_off, dst_off, in_stride, dst_stride) in ((1, 3, 65536, 76501), (7, 0, 40001, 46800), (13, 5, 65535, 76543)):
+        nb = 40
+        kinds = ("text_mtg", "random", "lz", "words", "same")
+        lens = [int(rs.randint(0, in_stride + 1)) if i % 5 else (in_stride if i % 10 else 0) for i in range(nb)]
+        blocks = [fuzzgen.gen(kinds[i % len(kinds)], 900 + i, lens[i]).tobytes() for i in range(nb)]
+        host = np.zeros(src_off + nb * in_stride + 64, dtype=np.uint8)
+        for i, b in enumerate(blocks):
+            host[src_off + i * in_stride:src_off + i * in_stride + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        d_src = torch.from_numpy(host).cuda()
+        d_len = torch.from_numpy(np.array(lens, dtype=np.int32)).cuda()
+        d_dst = torch.full((dst_off + nb * dst_stride + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+        out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        P.compress_blocks(d_src[src_off:], in_stride, nb, in_len=d_len, dst=d_dst[dst_off:], dst_stride=dst_stride,
+                          out_len=out_len)
+        torch.cuda.synchronize()
+        ol = out_len.cpu().numpy()
+        out = d_dst.cpu().numpy()
+        assert (out[:dst_off] == 0xA5).all()
+        for i, b in enumerate(blocks):
+            base = dst_off + i * dst_stride
+            want = oracle_lib.raw_compress(b)
+            assert ol[i] == len(want) and out[base:base + ol[i]].tobytes() == want, (src_off, i, lens[i])
+            assert (out[base + ol[i]:base + dst_stride] == 0xA5).all(), "wrote past the end of block %d" % i
