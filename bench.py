@@ -226,7 +226,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes},
             "workloads": extras,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # host baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.workload, 1024)
         print(json.dumps(line), flush=True)
     if dist_on:
