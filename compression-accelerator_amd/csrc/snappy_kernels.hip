@@ -5,17 +5,16 @@
 // result length (a9).  Output is byte-identical to software Snappy 1.1.8 (the parity target of
 // the reference's tests/swcompression.cc:45), not to the RTL's own stream.
 //
-// Mapping to the machine
-//   * one 64-lane wavefront (= one 64-thread workgroup) per <=64 KiB block;
-//   * the 16384 x uint16 hash table lives in LDS (32 KiB -> 5 blocks resident per CU out of
-//     160 KiB; nothing else is kept in LDS so that the 5th wave fits);
-//   * the greedy parse is serial in the reference; here the SCAN phase is speculated 64 probes
-//     at a time: between two matches the probe schedule is a pure function of the miss count
-//     (skip starts at 32 and grows by skip>>5 per miss), so lane k probes the k-th future
-//     position, a ballot finds the first hit and the table is rolled back behind it;
-//   * match extension compares 64 B (then 1 KiB) per step with a ballot for the first
-//     mismatch; literal bytes and split copy elements are written by all lanes;
-//   * input is read with coalesced/unaligned global loads (L1/L2), output written once.
+// Mapping to the machine (details at compress_one_block and the two kernels below)
+//   * one 64-lane wavefront per <=64 KiB block; the 16384 x uint16 hash table in LDS (32 KiB: four
+//     blocks per CU = one wave per SIMD) or, for the extra waves of the multi-wave kernel, in a
+//     generation-tagged table in global memory;
+//   * the greedy parse is serial in the reference; here 64 positions are probed at once -- 64
+//     consecutive bytes ("dense window", scalar walk over the ballot mask, prefix-sum packing of
+//     the elements) or the next 64 probes of the skip schedule ("strided batch") -- and the table
+//     ends up exactly as the serial parse leaves it;
+//   * long matches extend 64 B, then 1 KiB per step with a ballot; literal bytes and split copy
+//     elements are written by all lanes; incompressible blocks stream through the register file.
 //
 // No MFMA: this is byte/integer work bounded by HBM ("Roofline").
 #include <hip/hip_runtime.h>
@@ -48,7 +47,6 @@ static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Sna
 static constexpr uint32_t kMaxBlock = 65536u;
 static constexpr uint32_t kMaxTable = 16384u;
 static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
-  // CompressionAccelerator.scala:76-78
 
 // Probe schedule of the scan loop after a (re)start: off[k] = distance of the k-th probe from the
 // first one.  skip_0 = 32, off_{k+1} = off_k + (skip_k >> 5), skip_{k+1} = skip_k + (skip_k >> 5).
@@ -339,8 +337,8 @@ __device__ __forceinline__ uint64_t lanes_below(uint32_t k)  // bits 0..k-1, k i
 // positions are hashed, looked up and compared against their candidate at once; which of them the
 // serial parse actually visits is then a short scalar walk over the hit mask (a hit at lane j with
 // local match length ml sends the parse to lane j+ml, a miss to lane j+1), and the elements of the
-// window are packed by a wave prefix sum.  The lookups are exact because the window is cut before
-// the first lane whose bucket was already used by an earlier lane of the same window.
+// window are packed by a wave prefix sum.  The lookups are exact as long as no two INSERTED lanes
+// share a bucket; that is verified after the fact (commit, read back) and repaired by a redo.
 //
 // STRIDED BATCH (sc >= 32: the skip heuristic has accelerated).  Lane k takes the k-th future probe
 // of the schedule; the first hit wins and probes behind it are rolled back.
@@ -349,8 +347,8 @@ __device__ __forceinline__ uint64_t lanes_below(uint32_t k)  // bits 0..k-1, k i
 //  * LDS, 16384 x uint16, zeroed per block (32 KiB: four of them fit a CU, one per SIMD);
 //  * global memory (L2 / Infinity Cache), 16384 x uint32 entries tagged with a per-slot generation
 //    in the high half so that a new block needs no zeroing pass (an entry of another generation
-//    reads as 0 = empty).  Used by the second wave of a SIMD in the dual kernel, for which no LDS
-//    is left.
+//    reads as 0 = empty).  Used by the extra waves of a SIMD in the multi-wave kernel, for which no
+//    LDS is left.
 // NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
 // loads/stores with a vmcnt(0) wait after each.  The places that need "really re-read memory"
 // (other lanes of the same store may have won the bucket) use a compiler barrier.
