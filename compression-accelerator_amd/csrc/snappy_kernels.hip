@@ -891,6 +891,12 @@ __device__ __forceinline__ bool prefers_dual(const uint32_t *__restrict__ select
     return (uint64_t)select[0] * 10 > select[1];  // repeats > 10 % of the sampled positions
 }
 
+__global__ __launch_bounds__(64) void reset_launch_state_kernel(uint32_t *__restrict__ select)
+{
+    if (threadIdx.x < 3)
+        select[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(256) void sample_compressibility_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint32_t *__restrict__ select)
@@ -953,7 +959,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // instruction latencies overlap (a lone wave issues ~1 instruction per 10 cycles).  Wave 0 keeps
 // its table in LDS; the others have generation-tagged tables in global memory (one slot each in
 // `scratch`).  Persistent grid: all waves pull block indices from one device-wide counter (zeroed
-// by a memset node ahead of the launch), so the faster (LDS-table) waves take more of them and
+// by a tiny kernel ahead of the launch), so the faster (LDS-table) waves take more of them and
 // mixed workloads balance.  Measured on 64 KiB text blocks: 2 waves 42 GB/s, 3 waves 48, 4 waves 44
 // (register spills); one wave per SIMD (single kernel) 32.  With 3 waves a wave has 170 registers,
 // so no part of the block is kept in registers (incompressible data goes to the single kernel).
@@ -1189,11 +1195,9 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
     uint8_t *dst = static_cast<uint8_t *>(d_dst);
     const bool dual_ok = dual && dual->tables && n_blocks >= dual->min_blocks;
     const uint32_t *select = nullptr;
-    if (dual_ok) {  // [repeats, positions, next block] of this launch
-        hipError_t e = hipMemsetAsync(dual->select, 0, 3 * sizeof(uint32_t), stream);
-        if (e != hipSuccess)
-            return e;
-    }
+    if (dual_ok)  // [repeats, positions, next block] of this launch := 0.  (A kernel, not hipMemsetAsync:
+                  // captured into a hipGraph, the memset node made every replay after the first a no-op.)
+        hipLaunchKernelGGL(reset_launch_state_kernel, dim3(1), dim3(64), 0, stream, dual->select);
     if (dual_ok && dual->mode == kDualAuto) {
         // sample -> both kernels, each checks the verdict first (graph-capture safe: no host sync)
         const uint32_t ns = n_blocks < 64 ? n_blocks : 64;
