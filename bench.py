@@ -228,6 +228,9 @@ def main():
         }
         if not args.no_cpu and world == 1:  # host baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.workload, 1024)
+            if "text" in extras:  # the same oracle on the latency-bound workload, for scale (bounded: ~4 s)
+                t = cpu_baseline("text", 256, budget_s=4.0)
+                extras["text"]["cpu_port_GBps"] = {"1_thread": t["single_thread_GBps"], "%d_threads" % t["cores"]: t["value"]}
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()
