@@ -63,7 +63,7 @@ def make_input(kind, first_block, n_blocks, device):
     raise KeyError(kind)
 
 
-def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on, verify_blocks=8):
+def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on, verify_blocks=8, decompress=False):
     """Returns dict with timing of `steps` steps (max over ranks), kernel-only event times, sizes."""
     import torch
     import torch.distributed as dist
@@ -114,9 +114,22 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
     for j, b in enumerate(pick):
         want = oracle_lib.raw_compress(host_in[j])
         exact &= host_out[j, :lens[b]].tobytes() == want
+    # ---- the next row: GPU decompression of what was just produced, round trip checked
+    dec = None
+    if decompress:
+        back = torch.empty(n_blocks * BLOCK, dtype=torch.uint8, device=device)
+        P.uncompress_blocks(dst, P.SLOT_STRIDE, out_len, n_blocks, dst=back)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _, ulen, status = P.uncompress_blocks(dst, P.SLOT_STRIDE, out_len, n_blocks, dst=back)
+        e1.record()
+        torch.cuda.synchronize()
+        dec = {"ms": e0.elapsed_time(e1), "round_trip": bool(torch.equal(back, src)) and int(status.abs().sum().item()) == 0}
+        del back
     del src, dst
     return {"elapsed_s": elapsed, "kernel_ms": kernel_ms, "in_bytes": n_blocks * BLOCK, "out_bytes": out_bytes,
-            "bit_exact_sample": bool(exact), "n_blocks": n_blocks}
+            "bit_exact_sample": bool(exact), "n_blocks": n_blocks, "decompress": dec}
 
 
 def cpu_baseline(kind, sample_blocks, budget_s=12.0):
@@ -178,13 +191,15 @@ def main():
         for kind, nb in (("text", 16384), ("c5", 16384), ("mix", 16386)):
             if kind == args.workload:
                 continue
-            r = run_workload(P, kind, rank * nb, nb, 3, 1, device, dist_on)
+            r = run_workload(P, kind, rank * nb, nb, 3, 1, device, dist_on, decompress=True)
             k_ms = float(np.mean(r["kernel_ms"]))
             extras[kind] = {"input_GBps": round(r["in_bytes"] * world * 3 / r["elapsed_s"] / 1e9, 2),
                             "kernel_ms": round(k_ms, 3), "blocks_per_gpu": nb,
                             "compression_ratio": round(r["in_bytes"] / r["out_bytes"], 4),
                             "hbm_frac_in_plus_out": round((r["in_bytes"] + r["out_bytes"]) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                            "bit_exact_sample": r["bit_exact_sample"]}
+                            "bit_exact_sample": r["bit_exact_sample"],
+                            "gpu_decompress_GBps": round(r["in_bytes"] / (r["decompress"]["ms"] * 1e-3) / 1e9, 2),
+                            "gpu_round_trip": r["decompress"]["round_trip"]}
 
     exact_all = main_res["bit_exact_sample"]
     if dist_on:
