@@ -85,6 +85,20 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
     return finish(sc);
 }
 
+// Frees the multi-wave workspace that belongs to a stream which is about to be destroyed.
+void drop_dual_scratch(int dev, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lock(g_dual_mutex);
+    auto it = g_dual.find(std::make_pair(dev, stream));
+    if (it == g_dual.end())
+        return;
+    if (it->second.tables)
+        (void)hipFree(it->second.tables);
+    if (it->second.gen)
+        (void)hipFree(it->second.gen);
+    g_dual.erase(it);
+}
+
 thread_local int tl_hip_error = 0;
 thread_local int tl_rocc_error = 0;
 thread_local uint32_t tl_rocc_length = 0;  // the accelerator's latched `length` register
@@ -144,8 +158,11 @@ struct Workspace {
             buf[i] = nullptr;
             cap[i] = 0;
         }
-        if (stream)
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            drop_dual_scratch(device, stream);
             (void)hipStreamDestroy(stream);
+        }
         stream = nullptr;
         device = -1;
     }

@@ -304,3 +304,15 @@ def test_device_api_is_graph_capturable():
             want = oracle_lib.raw_compress(host[b * 65536:(b + 1) * 65536])
             got = dst[b * P.SLOT_STRIDE:b * P.SLOT_STRIDE + int(ol[b])].cpu().numpy().tobytes()
             assert got == want, (kind, b)
+
+
+def test_release_thread_resources_and_reuse():
+    """sz_release_thread_resources frees the host-API workspace (and the multi-wave workspace of its
+    stream); the next call simply builds them again."""
+    P = pkg()
+    data = fuzzgen.corpus("mtg")[:300000]
+    want = oracle_lib.raw_compress(data)
+    for _ in range(3):
+        assert P.compress(data) == want
+        P.lib().sz_release_thread_resources()
+    assert P.uncompress(P.compress(data)) == data
