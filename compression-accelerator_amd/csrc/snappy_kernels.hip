@@ -1115,6 +1115,62 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             st = kStatusNoSpace;
     }
 
+    // ---- windowed decode: the tags of 64 candidate element starts are decoded at once (lane l looks
+    // at compressed byte ip + l), then the elements that really start in the window are walked with
+    // v_readlane -- no dependent tag load per element.  Needs ip + 72 <= n; the tail below is serial.
+    while (st == 0 && (uint64_t)ip + 72 <= n) {
+        const uint64_t x = ld64(in + ip + lane);
+        const uint32_t tag = (uint32_t)x & 0xffu;
+        const uint32_t extra = (uint32_t)(x >> 8);
+        const uint32_t kind_v = tag & 3u;
+        const uint32_t l6 = tag >> 2;
+        uint32_t size_v, olen_v, aux_v;  // compressed size, produced bytes, (literal: header bytes | copy: offset)
+        if (kind_v == 0) {
+            const uint32_t nb = l6 < 60 ? 0u : l6 - 59u;
+            const uint32_t lenm1 = nb == 0 ? l6 : (nb == 4 ? extra : (extra & ((1u << (8 * nb)) - 1u)));
+            aux_v = 1 + nb;
+            olen_v = lenm1 + 1;        // wraps to 0 for 2^32: rejected below
+            size_v = aux_v + olen_v;   // may wrap for absurd lengths: the bound checks use 64 bits
+        } else if (kind_v == 1) {
+            size_v = 2;
+            olen_v = (l6 & 7u) + 4;
+            aux_v = ((tag >> 5) << 8) | (extra & 0xffu);
+        } else if (kind_v == 2) {
+            size_v = 3;
+            olen_v = l6 + 1;
+            aux_v = extra & 0xffffu;
+        } else {
+            size_v = 5;
+            olen_v = l6 + 1;
+            aux_v = extra;
+        }
+        uint32_t j = 0;
+        while (j < 64) {
+            const uint32_t kind = lane_get(kind_v, j), len = lane_get(olen_v, j), aux = lane_get(aux_v, j);
+            const uint32_t at = ip + j;
+            if (kind == 0) {
+                if (len == 0 || (uint64_t)at + aux + len > n || (uint64_t)op + len > ulen) {
+                    st = kStatusCorrupt;
+                    break;
+                }
+                wave_copy(out + op, in + at + aux, len, lane);
+                j += aux + len;  // (<= n - ip, no overflow)
+            } else {
+                if (aux == 0 || aux > op || (uint64_t)op + len > ulen) {
+                    st = kStatusCorrupt;
+                    break;
+                }
+                if (lane < len)
+                    out[op + lane] = out[op - aux + (lane % aux)];
+                j += lane_get(size_v, j);
+            }
+            op += len;
+        }
+        if (st != 0)
+            break;
+        ip += j;
+    }
+
     while (st == 0 && ip < n) {
         // tag + up to 4 trailing bytes in one go when they are in bounds
         uint32_t tag, extra = 0;

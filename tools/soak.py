@@ -30,6 +30,22 @@ while done < n_cases:
             if g != w:
                 bad += 1
                 print("MISMATCH", mode, c, len(g), len(w), flush=True)
+    # GPU decompression of the oracle's streams must give the inputs back
+    import torch
+    from pkg_loader import load_package
+    P = load_package()
+    nbk = len(blocks)
+    host = np.zeros((nbk, P.SLOT_STRIDE), dtype=np.uint8); clen = np.zeros(nbk, dtype=np.int32)
+    for i, c in enumerate(want):
+        host[i, :len(c)] = np.frombuffer(c, dtype=np.uint8); clen[i] = len(c)
+    d_src = torch.from_numpy(host).cuda().reshape(-1); d_len = torch.from_numpy(clen).cuda()
+    dstb, ulen, status = P.uncompress_blocks(d_src, P.SLOT_STRIDE, d_len, nbk)
+    torch.cuda.synchronize()
+    ul = ulen.cpu().numpy(); stt = status.cpu().numpy(); outb = dstb.cpu().numpy().reshape(nbk, 65536)
+    for i, b in enumerate(blocks):
+        if stt[i] != 0 or ul[i] != len(b) or outb[i, :len(b)].tobytes() != b:
+            bad += 1
+            print("DECOMPRESS MISMATCH", cases[i], int(stt[i]), int(ul[i]), flush=True)
     done += len(cases)
     print("%d cases, %d mismatches, %.0f s" % (done, bad, time.time() - t0), flush=True)
 print("soak done: %d cases x 2 kernels, %d mismatches" % (done, bad))
