@@ -1144,28 +1144,86 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             olen_v = l6 + 1;
             aux_v = extra;
         }
+        // ---- which lanes start an element?  (scalar walk; literal sizes are validated here)
+        uint64_t Pm = 0;
         uint32_t j = 0;
         while (j < 64) {
-            const uint32_t kind = lane_get(kind_v, j), len = lane_get(olen_v, j), aux = lane_get(aux_v, j);
-            const uint32_t at = ip + j;
-            if (kind == 0) {
-                if (len == 0 || (uint64_t)at + aux + len > n || (uint64_t)op + len > ulen) {
+            Pm |= 1ull << j;
+            if (lane_get(kind_v, j) == 0) {
+                const uint32_t len = lane_get(olen_v, j), hdr = lane_get(aux_v, j);
+                if (len == 0 || (uint64_t)ip + j + hdr + len > n) {
                     st = kStatusCorrupt;
                     break;
                 }
-                wave_copy(out + op, in + at + aux, len, lane);
-                j += aux + len;  // (<= n - ip, no overflow)
+                j += hdr + len;
             } else {
-                if (aux == 0 || aux > op || (uint64_t)op + len > ulen) {
-                    st = kStatusCorrupt;
-                    break;
-                }
-                if (lane < len)
-                    out[op + lane] = out[op - aux + (lane % aux)];
                 j += lane_get(size_v, j);
             }
-            op += len;
         }
+        if (st != 0)
+            break;
+        // ---- output offsets of the window's elements
+        const bool is_elem = (Pm >> lane) & 1;
+        const uint32_t olen = is_elem ? olen_v : 0u;
+        const uint32_t incl = wave_inclusive_sum(olen);
+        const uint32_t o_rel = incl - olen;  // offset inside this window's output
+        const uint32_t total = lane_get(incl, 63);
+        if ((uint64_t)op + total > ulen) {
+            st = kStatusCorrupt;
+            break;
+        }
+        const bool is_copy = is_elem && kind_v != 0;
+        if (__ballot(is_copy && (aux_v == 0 || aux_v > op + o_rel)) != 0) {
+            st = kStatusCorrupt;
+            break;
+        }
+        // A copy whose source ends before this window's output begins ("far") depends on nothing that
+        // is produced here, nor does a literal: those are all done at once, one element per lane,
+        // four bytes per step.  Copies that read this window's own output ("near") follow in order.
+        const bool far_copy = is_copy && aux_v >= o_rel + olen;
+        const bool near_copy = is_copy && !far_copy;
+        const bool small_lit = is_elem && kind_v == 0 && olen <= 64;
+        const bool big_lit = is_elem && kind_v == 0 && olen > 64;
+        {
+            const bool par = far_copy || small_lit;
+            const uint8_t *sp = small_lit ? in + ip + lane + aux_v : out + op + o_rel - aux_v;
+            uint8_t *dp = out + op + o_rel;
+            const uint32_t mylen = par ? olen : 0u;
+            // longest parallel element (wave max through the ballots of its bits; lengths <= 64)
+            uint32_t maxlen = 0;
+            for (int bit = 6; bit >= 0; bit--)
+                if (__ballot(mylen >= (maxlen | (1u << bit))) != 0)
+                    maxlen |= 1u << bit;
+            for (uint32_t i = 0; i < maxlen; i += 16) {
+                uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+                if (i + 4 <= mylen) w0 = ld32(sp + i);
+                if (i + 8 <= mylen) w1 = ld32(sp + i + 4);
+                if (i + 12 <= mylen) w2 = ld32(sp + i + 8);
+                if (i + 16 <= mylen) w3 = ld32(sp + i + 12);
+                if (i + 4 <= mylen) __builtin_memcpy(dp + i, &w0, 4);
+                if (i + 8 <= mylen) __builtin_memcpy(dp + i + 4, &w1, 4);
+                if (i + 12 <= mylen) __builtin_memcpy(dp + i + 8, &w2, 4);
+                if (i + 16 <= mylen) __builtin_memcpy(dp + i + 12, &w3, 4);
+            }
+            // tails: up to 3 bytes per element
+            const uint32_t tail0 = mylen & ~3u;
+            for (uint32_t k = 0; k < 3; k++)
+                if (tail0 + k < mylen)
+                    dp[tail0 + k] = sp[tail0 + k];
+        }
+        // literals longer than 64 bytes: cooperative copies (their data comes from the input)
+        for (uint64_t B = __ballot(big_lit); B; B &= B - 1) {
+            const uint32_t e = ctz64(B);
+            wave_copy(out + op + lane_get(o_rel, e), in + ip + e + lane_get(aux_v, e), lane_get(olen_v, e), lane);
+        }
+        // near copies, in stream order (they may read what the steps above and each other wrote)
+        for (uint64_t N = __ballot(near_copy); N; N &= N - 1) {
+            const uint32_t e = ctz64(N);
+            const uint32_t len = lane_get(olen_v, e), off = lane_get(aux_v, e), o = op + lane_get(o_rel, e);
+            if (lane < len)
+                out[o + lane] = out[o - off + (lane % off)];
+        }
+        op += total;
         if (st != 0)
             break;
         ip += j;
