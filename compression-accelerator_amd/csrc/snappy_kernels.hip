@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
     // ---- windowed decode: the tags of 64 candidate element starts are decoded at once (lane l looks
     // at compressed byte ip + l), then the elements that really start in the window are walked with
     // v_readlane -- no dependent tag load per element.  Needs ip + 72 <= n; the tail below is serial.
-    while (st == 0 && (uint64_t)ip + 72 <= n) {
+    while (st == 0 && (uint64_t)ip + 72 <= n && n <= 0x7fffffffu) {  // (32-bit offset sums below)
         const uint64_t x = ld64(in + ip + lane);
         const uint32_t tag = (uint32_t)x & 0xffu;
         const uint32_t extra = (uint32_t)(x >> 8);

@@ -316,3 +316,56 @@ def test_release_thread_resources_and_reuse():
         assert P.compress(data) == want
         P.lib().sz_release_thread_resources()
     assert P.uncompress(P.compress(data)) == data
+
+
+def test_corrupted_streams_never_write_out_of_bounds():
+    """Bit-flipped, truncated and spliced streams: the decompressor may report an error or (when the
+    damage happens to be harmless) decode something, but it must stay inside its output slot."""
+    import torch
+    P = pkg()
+    rs = np.random.RandomState(2024)
+    good = [oracle_lib.raw_compress(fuzzgen.gen(k, 50 + i, int(rs.randint(200, 65537))).tobytes())
+            for i, k in enumerate(("text_mtg", "lz", "words", "runs", "random", "alpha4", "periodic", "sparse") * 4)]
+    streams = []
+    for i in range(1500):
+        s = bytearray(good[i % len(good)])
+        mode = i % 4
+        if mode == 0:
+            for _ in range(int(rs.randint(1, 6))):
+                s[int(rs.randint(0, len(s)))] ^= 1 << int(rs.randint(0, 8))
+        elif mode == 1:
+            s = s[:int(rs.randint(1, len(s)))]
+        elif mode == 2:
+            other = good[int(rs.randint(0, len(good)))]
+            cut = int(rs.randint(1, len(s)))
+            s = s[:cut] + other[int(rs.randint(0, len(other))):]
+        else:
+            pos = int(rs.randint(0, len(s)))
+            s[pos:pos] = bytes(rs.randint(0, 256, size=int(rs.randint(1, 9))).astype(np.uint8))
+        streams.append(bytes(s[:P.SLOT_STRIDE]))
+    nb = len(streams)
+    host = np.zeros((nb, P.SLOT_STRIDE), dtype=np.uint8)
+    clen = np.zeros(nb, dtype=np.int32)
+    for i, c in enumerate(streams):
+        host[i, :len(c)] = np.frombuffer(c, dtype=np.uint8)
+        clen[i] = len(c)
+    stride = 65536 + 256  # slots are adjacent: a write past one slot's capacity lands in its neighbour
+    dst = torch.full((nb * stride,), 0x5A, dtype=torch.uint8, device="cuda")
+    d_src = torch.from_numpy(host).cuda().reshape(-1)
+    d_len = torch.from_numpy(clen).cuda()
+    out_len = torch.empty(nb, dtype=torch.int32, device="cuda")
+    status = torch.empty(nb, dtype=torch.int32, device="cuda")
+    import ctypes
+    rc = P.lib().sz_uncompress_blocks_hip(ctypes.c_void_p(d_src.data_ptr()), P.SLOT_STRIDE, ctypes.c_void_p(d_len.data_ptr()),
+                                          nb, ctypes.c_void_p(dst.data_ptr()), stride, ctypes.c_void_p(out_len.data_ptr()),
+                                          ctypes.c_void_p(status.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    out = dst.cpu().numpy().reshape(nb, stride)
+    st = status.cpu().numpy()
+    ol = out_len.cpu().numpy()
+    assert set(np.unique(st)) <= {0, P.SZ_ECORRUPT, P.SZ_ENOSPC}
+    assert (st != 0).sum() > nb // 2  # most of the damage is detected
+    for i in range(nb):
+        if st[i] == 0:
+            assert oracle_lib.uncompress(streams[i]) == out[i, :ol[i]].tobytes()
