@@ -29,16 +29,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Diagnostic build only (tools/chainprof.hip compiles this file with -DSZ_PROF): cycle stamps per
 // phase, summed per block into g_prof.  Expands to nothing in the product build.
 #ifdef SZ_PROF
-__device__ unsigned long long g_prof[32];
+__device__ unsigned long long g_prof[64];  // [0,32): waves with the table in LDS, [32,64): in global memory
 #define PROF_DECL unsigned long long pt_ = 0, pacc_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned pcnt_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
 #define PROF_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt_) :: "memory"); } while (0)
 #define PROF_LAP(i) do { unsigned long long t2_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
+#define PROF_LAPV(i) do { unsigned long long t2_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
 #define PROF_ADD(i, v) do { pacc_[i] += (unsigned long long)(v); pcnt_[i]++; } while (0)
-#define PROF_FLUSH() do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; i_++) { atomicAdd(&g_prof[i_], pacc_[i_]); atomicAdd(&g_prof[16 + i_], (unsigned long long)pcnt_[i_]); } } } while (0)
+#define PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) { const int b_ = tab.in_lds ? 0 : 32; for (int i_ = 0; i_ < 16; i_++) { atomicAdd(&g_prof[b_ + i_], pacc_[i_]); atomicAdd(&g_prof[b_ + 16 + i_], (unsigned long long)pcnt_[i_]); } } } while (0)
 #else
 #define PROF_DECL
 #define PROF_START() do { } while (0)
 #define PROF_LAP(i) do { } while (0)
+#define PROF_LAPV(i) do { } while (0)
 #define PROF_ADD(i, v) do { } while (0)
 #define PROF_FLUSH() do { } while (0)
 #endif
@@ -147,6 +149,7 @@ __device__ __forceinline__ uint32_t matchlen32(const u32x4 &a, const u32x4 &a2, 
 
 // Cooperative byte copy by one wave, dst-aligned 16-byte stores in the bulk; long copies stream
 // with non-temporal loads/stores, 16 KiB in flight.
+template <bool kDeep = true>
 __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s,
                                           uint32_t len, uint32_t lane)
 {
@@ -163,7 +166,7 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t
     len -= head;
     const uint32_t nvec = len >> 4;
     uint32_t i = lane;
-    if (nvec >= 1024) {
+    if (kDeep && nvec >= 1024) {
         for (; i + 960 < nvec; i += 1024) {
             u32x4 q[16];
 #pragma unroll
@@ -193,6 +196,7 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t
 
 // Literal element (a7): tag (len-1)<<2 for len<=60 (CompressionAccelerator.scala:172,231-233);
 // software Snappy tags 60/61 + 1/2 little-endian bytes of len-1 for longer runs (len<=65536).
+template <bool kDeep = true>
 __device__ __forceinline__ uint32_t emit_literal(uint8_t *__restrict__ out, uint32_t op,
                                                  const uint8_t *__restrict__ s, uint32_t len,
                                                  uint32_t lane)
@@ -211,7 +215,7 @@ __device__ __forceinline__ uint32_t emit_literal(uint8_t *__restrict__ out, uint
     }
     if (lane < hdr)
         out[op + lane] = (uint8_t)(word >> (8 * lane));
-    wave_copy(out + op + hdr, s, len, lane);
+    wave_copy<kDeep>(out + op + hdr, s, len, lane);
     return op + hdr + len;
 }
 
@@ -385,7 +389,7 @@ struct HashTab {
 };
 
 // One block by one wavefront.  kChunks = 1 KiB chunks of the block kept in registers.
-template <int kBlkChunks>
+template <int kBlkChunks, bool kLean = false>
 __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const uint8_t *__restrict__ in,
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
                                                        uint32_t lane)
@@ -406,7 +410,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
         const uint32_t ip_limit = n - kInputMargin;  // positions <= n-16 may be probed
 
         // probe schedule in registers: lane l holds off[64*j + l] and off[64*j + l + 1]
-        const uint32_t *po = g_probe.off + lane;
+        // (lean variant, for the multi-wave kernel's compressible data: the schedule stays in memory and
+        // the first scan gets no prefetch, which frees ~20 registers per lane for a higher occupancy)
+        const uint32_t *po = g_probe.off + (kLean ? 0u : lane);
         const uint32_t Pr1 = po[64], Pr2 = po[128], Pr3 = po[192], Pr4 = po[256], Pr5 = po[320];
         const uint32_t Pn1 = po[65], Pn2 = po[129], Pn3 = po[193], Pn4 = po[257], Pn5 = po[321];
         const uint32_t Pr0b = po[32], Pn0b = po[33];  // probes 32..63 in lanes 0..31 (first strided batch)
@@ -450,11 +456,13 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
         }
         const uint32_t blk_op = op;  // the literal must start here for the prediction to hold
 
-        if (lane < 32 && 1 + Pn0b <= ip_limit) pv0b = ld32(in + 1 + Pr0b);
-        if (1 + Pn1 <= ip_limit) pv1 = ld32(in + 1 + Pr1);
-        if (1 + Pn2 <= ip_limit) pv2 = ld32(in + 1 + Pr2);
-        if (1 + Pn3 <= ip_limit) pv3 = ld32(in + 1 + Pr3);
-        if (1 + Pn4 <= ip_limit) pv4 = ld32(in + 1 + Pr4);
+        if (!kLean) {
+            if (lane < 32 && 1 + Pn0b <= ip_limit) pv0b = ld32(in + 1 + Pr0b);
+            if (1 + Pn1 <= ip_limit) pv1 = ld32(in + 1 + Pr1);
+            if (1 + Pn2 <= ip_limit) pv2 = ld32(in + 1 + Pr2);
+            if (1 + Pn3 <= ip_limit) pv3 = ld32(in + 1 + Pr3);
+            if (1 + Pn4 <= ip_limit) pv4 = ld32(in + 1 + Pr4);
+        }
 
         // (a2) zeroed uint16 table, T = clamp(pow2 >= n, 256, 16384)
         uint32_t log2T = 8;
@@ -471,7 +479,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
                 big_len = len;
                 op += 3 + len;
             } else {
-                op = emit_literal(out, op, in + from, len, lane);
+                op = emit_literal<!kLean>(out, op, in + from, len, lane);
             }
         };
 
@@ -479,7 +487,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
         bool chain = false;      // P ends a copy: insert P-1, probe P
         uint32_t sc = 0;         // scan: index of the next probe
         uint32_t scan_base = 1;  // scan: position of probe 0 (skip == 32 there)
-        bool first_scan = true;  // pv[] belongs to the scan that starts at 1
+        bool first_scan = !kLean;  // pv[] belongs to the scan that starts at 1
         PROF_DECL
         PROF_START();
         for (;;) {
@@ -499,15 +507,16 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
                 const bool valid = pos < ip_limit;  // a prefix of the lanes; lane `first` is valid
                 const bool wide = pos + 32 <= n;    // a2 really holds bytes 16..31 (a prefix too)
                 const uint32_t h = (a.x * kHashMul) >> shift;  // a, a2: loaded by load_window(W0)
-                PROF_LAP(0);
+                PROF_LAPV(0);
                 if (chain && lane == 0)
                     tab.put(h, pos);  // the reference inserts P-1 before it looks P up
                 const bool spec = valid && lane >= first;
                 uint32_t cand = 0;
                 if (spec)
                     cand = tab.get(h);  // table as of the start of the window
-                const uint32_t nvalid = ip_limit - W0 < 64 ? ip_limit - W0 : 64;  // W0 < ip_limit
-                PROF_LAP(1);
+                // lanes that may be probed: 63 at most (lane 63 only lends its bytes; see the walk)
+                const uint32_t nvalid = ip_limit - W0 < 63 ? ip_limit - W0 : 63;  // W0 < ip_limit
+                PROF_LAPV(1);
                 // candidates' bytes: unpredicated (cand < pos <= n-16, or 0 for lanes without one)
                 const u32x4 c = ld128(in + cand);
                 const u32x4 c2 = ld128(in + (cand + 16 < last16 ? cand + 16 : last16));
@@ -519,7 +528,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
                 const uint32_t mlw = ml == mcap ? 64u : ml;  // for the walk: a long match ends the window
                 const uint64_t Hm_all = __ballot(hit);
                 const uint64_t E16 = __ballot(hit && ml == mcap);  // lanes whose match must be extended
-                PROF_LAP(2);
+                PROF_LAPV(2);
 
                 // ---- scalar walk over the hit mask: which lanes does the serial parse visit?
                 // The lookups above are exact as long as no two INSERTED lanes of the window share a
@@ -554,31 +563,44 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
                     z &= z >> 16;
                     const uint32_t lead = (Hm ? ctz64(Hm) : lim) - first;  // misses before the first hit
                     if (z == 0 && (chain || sc + lead <= 31)) {
-                        uint32_t jh = 64;
-                        for (;;) {
-                            const uint64_t t = Hm >> j;
-                            if (t == 0)
-                                break;
-                            const uint32_t k = ctz64(t);
-                            jh = j + k;
-                            V |= ((2ull << k) - 1) << j;  // lanes j..jh (k <= 63)
-                            j = jh + lane_get(mlw, jh);
-                            if (j >= lim)
-                                break;
-                        }
-                        Hp = Hm & V;
-                        if (j < lim) {  // trailing misses up to the end of the usable lanes
-                            V |= lanes_below(lim - j) << j;
+                        // Every lane works out where the parse goes from it: to the next hit at or after
+                        // it and then past that hit's match (63 = out of the window; lane 63 is never
+                        // probed, so it can stand for "out").  The serial part is then one v_readlane per
+                        // element: S collects the lanes at which a literal run or a hit begins.
+                        const uint64_t tl = Hm >> lane;
+                        const uint32_t nh = (lane + (uint32_t)__builtin_ctzll(tl | (1ull << 63))) & 63u;
+                        const uint32_t m_nh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nh << 2), (int)mlw);
+                        const uint32_t tgt = nh + m_nh;
+                        const uint32_t vJ = (tl != 0 && tgt < lim) ? tgt : 63u;
+                        uint64_t S = 0;
+                        uint32_t jj = first;
+                        do {
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                S |= 1ull << jj;
+                                jj = lane_get(vJ, jj);
+                            }
+                        } while (jj != 63u);
+                        S &= ~(1ull << 63);
+                        const uint32_t s_last = 63u - (uint32_t)__builtin_clzll(S);  // (lane `first` is in S)
+                        // path hits = the first hit of every segment [start, next start): the borrow of
+                        // Hm - S runs from a start up to the first hit above it and clears it
+                        Hp = Hm & ~(Hm - S);
+                        if ((Hm >> s_last) == 0) {  // no hit after the last start: trailing misses up to lim
+                            V = ((Hp << 1) | (1ull << lim)) - S;  // [start, hit] of each element + [s_last, lim)
                             if (Hp || chain) {
-                                lit_lane = j;
-                                new_scan_base = W0 + j + 1;
-                                s = lim - j - 1;
+                                lit_lane = s_last;
+                                new_scan_base = W0 + s_last + 1;
+                                s = lim - s_last - 1;
                             } else {
-                                s = sc + lim - j;
+                                s = sc + lim - s_last;
                             }
                             ch = false;
                             j = lim;
                         } else {
+                            V = (Hp << 1) - S;
+                            const uint32_t jh = 63u - (uint32_t)__builtin_clzll(Hp);
+                            j = jh + lane_get(mlw, jh);
                             ch = true;
                             s = 0;
                             if ((E16 >> jh) & 1)
@@ -633,6 +655,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
                             }
                         }
                     }
+                    PROF_LAPV(8);
                     // ---- commit the inserts of the visited path, then check that none was lost
                     const bool ins_lane = ((V | Ins) >> lane) & 1;
                     uint32_t w = pos & 0xffffu;
@@ -642,6 +665,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
                         w = tab.get(h);
                     }
                     uint64_t L = __ballot(ins_lane && w != (pos & 0xffffu));
+                    PROF_LAPV(9);
                     if (L == 0)
                         break;
                     // two inserted lanes share a bucket: roll back (both read the same old entry) and
@@ -744,7 +768,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
             // ======================================================= strided batch (sc >= 32)
             const uint32_t n0 = sc;
             uint32_t p, pn;
-            const bool aligned = ((n0 & 63u) == 0 && n0 < 384) || n0 == 32;
+            const bool aligned = !kLean && (((n0 & 63u) == 0 && n0 < 384) || n0 == 32);
             const uint32_t bsel = n0 >> 6;  // 0 only for the half batch n0 == 32
             uint32_t cap = 64;  // lanes allowed in this batch
             if (aligned) {
@@ -860,7 +884,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
         }
     }
     if (next_emit < n)  // blocks shorter than the 15-byte margin are one literal
-        op = emit_literal(out, op, in + next_emit, n - next_emit, lane);
+        op = emit_literal<!kLean>(out, op, in + next_emit, n - next_emit, lane);
     return poisoned ? 0xfffffffeu : op;
 }
 
@@ -968,6 +992,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #endif
 static constexpr int kGroupWaves = SZ_GROUP_WAVES;
 static constexpr int kDualChunks = kGroupWaves == 2 ? 24 : 0;
+static constexpr bool kDualLean = kGroupWaves >= 3;
 __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_eu(kGroupWaves, kGroupWaves))) void compress_blocks_dual_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
@@ -1007,7 +1032,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
             }
             tab.tag = gen << 16;
         }
-        const uint32_t op = compress_one_block<kDualChunks>(tab, src + (uint64_t)b * in_stride, n,
+        const uint32_t op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
         if (lane == 0)
             out_len[b] = op;
