@@ -35,7 +35,7 @@ __device__ unsigned long long g_prof[64];  // [0,32): waves with the table in LD
 #define PROF_LAP(i) do { unsigned long long t2_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
 #define PROF_LAPV(i) do { unsigned long long t2_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
 #define PROF_ADD(i, v) do { pacc_[i] += (unsigned long long)(v); pcnt_[i]++; } while (0)
-#define PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) { const int b_ = tab.in_lds ? 0 : 32; for (int i_ = 0; i_ < 16; i_++) { atomicAdd(&g_prof[b_ + i_], pacc_[i_]); atomicAdd(&g_prof[b_ + 16 + i_], (unsigned long long)pcnt_[i_]); } } } while (0)
+#define PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) { const int b_ = Tab::kInLds ? 0 : 32; for (int i_ = 0; i_ < 16; i_++) { atomicAdd(&g_prof[b_ + i_], pacc_[i_]); atomicAdd(&g_prof[b_ + 16 + i_], (unsigned long long)pcnt_[i_]); } } } while (0)
 #else
 #define PROF_DECL
 #define PROF_START() do { } while (0)
@@ -356,25 +356,28 @@ __device__ __forceinline__ uint64_t lanes_below(uint32_t k)  // bits 0..k-1, k i
 // NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
 // loads/stores with a vmcnt(0) wait after each.  The places that need "really re-read memory"
 // (other lanes of the same store may have won the bucket) use a compiler barrier.
+template <bool in_lds>
 struct HashTab {
     uint16_t *lds;
     uint32_t *glob;
     uint32_t tag;  // generation << 16
-    bool in_lds;
+    static constexpr bool kInLds = in_lds;
 
     __device__ __forceinline__ uint32_t get(uint32_t h) const
     {
         if (in_lds)
-            return lds[h];
-        const uint32_t e = glob[h];
+            return __hip_atomic_load(lds + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        // (relaxed wave-scope atomics = plain global loads/stores that the compiler may neither
+        // forward nor merge: other lanes of this wave write the same entries)
+        const uint32_t e = __hip_atomic_load(glob + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         return (e & 0xffff0000u) == tag ? (e & 0xffffu) : 0u;
     }
     __device__ __forceinline__ void put(uint32_t h, uint32_t v) const
     {
         if (in_lds)
-            lds[h] = (uint16_t)v;
+            __hip_atomic_store(lds + h, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         else
-            glob[h] = tag | (v & 0xffffu);
+            __hip_atomic_store(glob + h, tag | (v & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     // (a2) table of T = 2^log2T entries, all empty
     __device__ __forceinline__ void clear(uint32_t log2T, uint32_t lane) const
@@ -389,8 +392,8 @@ struct HashTab {
 };
 
 // One block by one wavefront.  kChunks = 1 KiB chunks of the block kept in registers.
-template <int kBlkChunks, bool kLean = false>
-__device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const uint8_t *__restrict__ in,
+template <int kBlkChunks, bool kLean, typename Tab>
+__device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uint8_t *__restrict__ in,
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
                                                        uint32_t lane)
 {
@@ -744,9 +747,14 @@ __device__ __forceinline__ uint32_t compress_one_block(const HashTab &tab, const
                     }
                     const uint32_t incl = wave_inclusive_sum(cnt);
                     uint8_t *o = out + op + (incl - cnt);
+#ifdef SZ_ABLATION
+                    if (!(flags & 0x400u))  // timing ablation: no element stores
+#endif
+                    {
                     if (cnt >= 1) o[0] = (uint8_t)word;
                     if (cnt >= 2) o[1] = (uint8_t)(word >> 8);
                     if (cnt >= 3) o[2] = (uint8_t)(word >> 16);
+                    }
                     op += lane_get(incl, 63);
                 }
                 PROF_LAP(4);
@@ -971,8 +979,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             out_len[b] = 0xffffffffu;
         return;
     }
-    const HashTab tab{lds_tab, nullptr, 0u, true};
-    const uint32_t op = compress_one_block<64>(tab, src + (uint64_t)b * in_stride, n,
+    const HashTab<true> tab{lds_tab, nullptr, 0u};
+    const uint32_t op = compress_one_block<64, false>(tab, src + (uint64_t)b * in_stride, n,
                                                dst + (uint64_t)b * dst_stride, flags, lane);
     if (lane == 0)
         out_len[b] = op;  // (a9)
@@ -996,7 +1004,7 @@ static constexpr bool kDualLean = kGroupWaves >= 3;
 __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_eu(kGroupWaves, kGroupWaves))) void compress_blocks_dual_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
-    uint32_t *__restrict__ out_len, uint32_t flags, uint32_t *__restrict__ scratch_tables,
+    uint32_t *__restrict__ out_len, uint32_t flags, uint32_t *scratch_tables,
     uint32_t *__restrict__ scratch_gen, uint32_t *__restrict__ select, uint32_t auto_mode)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
@@ -1022,7 +1030,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
                 out_len[b] = 0xffffffffu;
             continue;
         }
-        HashTab tab{lds_tab, my_glob, 0u, wave == 0};
+        uint32_t op;
         if (wave >= 1) {
             gen = (gen + 1) & 0xffffu;
             if (gen == 0) {  // generation wrapped: start over from an all-zero table
@@ -1030,10 +1038,14 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
                     my_glob[i] = 0;
                 gen = 1;
             }
-            tab.tag = gen << 16;
-        }
-        const uint32_t op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
+            const HashTab<false> tab{nullptr, my_glob, gen << 16};
+            op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
+        } else {
+            const HashTab<true> tab{lds_tab, nullptr, 0u};
+            op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
+                                                            dst + (uint64_t)b * dst_stride, flags, lane);
+        }
         if (lane == 0)
             out_len[b] = op;
     }
