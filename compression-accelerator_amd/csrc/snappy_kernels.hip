@@ -422,18 +422,51 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         // The first scan of a block starts at 1: fetch the shingles of its far probe positions now
         // (one HBM latency for the whole block instead of one per batch when nothing matches).
         uint32_t pv0b = 0, pv1 = 0, pv2 = 0, pv3 = 0, pv4 = 0;
-        // 32 bytes per lane of the NEXT dense window (positions W .. W+63), loaded one step ahead of
-        // use.  Addresses are clamped to the block instead of predicated; lanes past the limit are
-        // masked out of every decision.
+        // Bytes of the dense windows.  Lane l of a window starting at W needs bytes [W+l, W+l+32): 64
+        // overlapping 32-byte strings out of ~100 distinct bytes.  Loading them per lane costs the L1
+        // ~190 tag lookups per window (the vector-memory pipeline is what bounds compressible data:
+        // profiles/r01_text_pmc.txt), so instead 256-byte stretches of the block are kept in
+        // registers -- buffer k = bytes [128k, 128k+256), one dword per lane, fetched by one coalesced
+        // load, the next one always prefetched -- and each window is cut out of its buffer with lane
+        // shuffles (ds_bpermute: LDS crossbar, no memory access) and v_alignbyte.
         const uint32_t last16 = n - 16;  // n >= 15 here; (n == 15: no position is probed at all)
         u32x4 a = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
-        auto load_window = [&](uint32_t W) {
-            const uint32_t q = W + lane;
-            a = ld128(in + (q < last16 ? q : last16));
-            a2 = ld128(in + (q + 16 < last16 ? q + 16 : last16));
+        uint32_t wcur = 0, wnxt = 0, kcur = 0;  // buffers kcur and kcur + 1
+        auto load_buf = [&](uint32_t k) -> uint32_t {
+            const uint32_t o = (k << 7) + 4u * lane;
+            const uint32_t oc = o < n - 4u ? o : n - 4u;  // stay inside the block ...
+            const uint32_t sh = o - oc < 3u ? o - oc : 3u;
+            return ld32(in + oc) >> (8u * sh);             // ... and keep its last bytes where they belong
         };
-        if (n >= 16)
-            load_window(1);
+        auto cut_window = [&](uint32_t W) {  // a, a2 := bytes [W+lane, W+lane+32); needs kcur == W >> 7
+            const uint32_t s0 = (W & 127u) + lane;  // <= 190: dwords s0/4 .. s0/4+8 <= 55 of the buffer
+            const uint32_t i0 = (s0 >> 2) << 2, sh = s0 & 3u;
+            uint32_t d[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++)
+                d[k] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i0 + 4 * k), (int)wcur);
+            a.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+            a.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+            a.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+            a.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
+            a2.x = __builtin_amdgcn_alignbyte(d[5], d[4], sh);
+            a2.y = __builtin_amdgcn_alignbyte(d[6], d[5], sh);
+            a2.z = __builtin_amdgcn_alignbyte(d[7], d[6], sh);
+            a2.w = __builtin_amdgcn_alignbyte(d[8], d[7], sh);
+        };
+        auto load_window = [&](uint32_t W) {
+            const uint32_t k = W >> 7;
+            if (k != kcur) {
+                wcur = k == kcur + 1 ? wnxt : load_buf(k);
+                wnxt = load_buf(k + 1);
+                kcur = k;
+            }
+            cut_window(W);
+        };
+        if (n >= 16) {
+            wcur = load_buf(0);
+            wnxt = load_buf(1);
+        }
 
         // Whole-block register prefetch (blocks >= 16 KiB), issued right behind the probe loads above
         // (measured: waiting for those to land first makes HBM reads exactly 1.00x the block but costs
@@ -486,6 +519,25 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             }
         };
 
+        // Head of the next dense window (it starts at Wn; chainN: lane 0 is the end of a copy), run one
+        // step ahead: its bytes, hash, the insert of P-1 and the table lookup are issued as soon as the
+        // window's start is known, and complete under the stores of the elements of the window before.
+        uint32_t hN = 0, candN = 0;
+        auto prep = [&](uint32_t Wn, bool chainN) {
+            const uint32_t firstN = chainN ? 1u : 0u;
+            if (Wn + firstN >= ip_limit)
+                return;  // nothing is probed there: the main loop ends
+            load_window(Wn);
+            const uint32_t posN = Wn + lane;
+            hN = (a.x * kHashMul) >> shift;
+            if (chainN && lane == 0)
+                tab.put(hN, posN);  // the reference inserts P-1 before it looks P up
+            candN = 0;
+            if (posN < ip_limit && lane >= firstN)
+                candN = tab.get(hN);  // table as of the start of the window
+        };
+        prep(1, false);
+
         uint32_t P = 1;          // next position to probe
         bool chain = false;      // P ends a copy: insert P-1, probe P
         uint32_t sc = 0;         // scan: index of the next probe
@@ -509,14 +561,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 const uint32_t pos = W0 + lane;
                 const bool valid = pos < ip_limit;  // a prefix of the lanes; lane `first` is valid
                 const bool wide = pos + 32 <= n;    // a2 really holds bytes 16..31 (a prefix too)
-                const uint32_t h = (a.x * kHashMul) >> shift;  // a, a2: loaded by load_window(W0)
+                const uint32_t h = hN;  // hash, insert of P-1 and lookup: done ahead by prep(W0, chain, .)
                 PROF_LAPV(0);
-                if (chain && lane == 0)
-                    tab.put(h, pos);  // the reference inserts P-1 before it looks P up
                 const bool spec = valid && lane >= first;
-                uint32_t cand = 0;
-                if (spec)
-                    cand = tab.get(h);  // table as of the start of the window
+                const uint32_t cand = candN;
                 // lanes that may be probed: 63 at most (lane 63 only lends its bytes; see the walk)
                 const uint32_t nvalid = ip_limit - W0 < 63 ? ip_limit - W0 : 63;  // W0 < ip_limit
                 PROF_LAPV(1);
@@ -714,8 +762,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         next_emit = P;
                     else if (lit_lane < 64)
                         next_emit = W0 + lit_lane;
-                    if (chain || sc <= 31)
-                        load_window(P - (chain ? 1u : 0u));
+                    if (chain || sc <= 31) {
+                        prep(P - (chain ? 1u : 0u), chain);
+                    }
                 }
                 first_scan = first_scan && !Hp && (scan_base == 1);
 
@@ -767,7 +816,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     chain = true;
                     sc = 0;
                     next_emit = P;
-                    load_window(P - 1);
+                    prep(P - 1, true);
                 }
                 PROF_LAP(5);
                 continue;
@@ -863,7 +912,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             sc = 0;
             next_emit = P;
             first_scan = false;
-            load_window(P - 1);
+            prep(P - 1, true);
             PROF_LAP(7);
         }
         PROF_FLUSH();
