@@ -361,6 +361,7 @@ struct HashTab {
     uint16_t *lds;
     uint32_t *glob;
     uint32_t tag;  // generation << 16
+    uint32_t *bm;  // global home only: 16384-bit scratch bitmap in LDS (all zero between uses)
     static constexpr bool kInLds = in_lds;
 
     __device__ __forceinline__ uint32_t get(uint32_t h) const
@@ -709,21 +710,42 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     PROF_LAPV(8);
                     // ---- commit the inserts of the visited path, then check that none was lost
                     const bool ins_lane = ((V | Ins) >> lane) & 1;
-                    uint32_t w = pos & 0xffffu;
-                    if (ins_lane) {
-                        tab.put(h, pos);
-                        asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
-                        w = tab.get(h);
+                    uint64_t L;
+                    if constexpr (Tab::kInLds) {
+                        uint32_t w = pos & 0xffffu;
+                        if (ins_lane) {
+                            tab.put(h, pos);
+                            asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
+                            w = tab.get(h);
+                        }
+                        L = __ballot(ins_lane && w != (pos & 0xffffu));
+                        PROF_LAPV(9);
+                        if (L == 0)
+                            break;
+                        // two inserted lanes share a bucket: roll back (both read the same old entry) and
+                        // keep the lanes before the second user; the redo cannot conflict again
+                        asm volatile("" ::: "memory");
+                        if (ins_lane)
+                            tab.put(h, cand);
+                    } else {
+                        // Table in global memory: a read-back would be 64 more L2 misses on the critical
+                        // path.  Shared buckets are found in a 16384-bit LDS bitmap instead (atomic OR:
+                        // of the lanes with one bucket exactly one sees its bit clear); the table is
+                        // written only once the path is final, so there is nothing to roll back.
+                        const uint32_t bit = 1u << (h & 31u);
+                        uint32_t old = 0;
+                        if (ins_lane)
+                            old = __hip_atomic_fetch_or(tab.bm + (h >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        L = __ballot(ins_lane && (old & bit));
+                        if (ins_lane)
+                            __hip_atomic_store(tab.bm + (h >> 5), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        PROF_LAPV(9);
+                        if (L == 0) {
+                            if (ins_lane)
+                                tab.put(h, pos);
+                            break;
+                        }
                     }
-                    uint64_t L = __ballot(ins_lane && w != (pos & 0xffffu));
-                    PROF_LAPV(9);
-                    if (L == 0)
-                        break;
-                    // two inserted lanes share a bucket: roll back (both read the same old entry) and
-                    // keep the lanes before the second user; the redo cannot conflict again
-                    asm volatile("" ::: "memory");
-                    if (ins_lane)
-                        tab.put(h, cand);
                     uint32_t cut = 64;
                     while (L) {
                         const uint32_t hv = lane_get(h, ctz64(L));
@@ -1028,7 +1050,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             out_len[b] = 0xffffffffu;
         return;
     }
-    const HashTab<true> tab{lds_tab, nullptr, 0u};
+    const HashTab<true> tab{lds_tab, nullptr, 0u, nullptr};
     const uint32_t op = compress_one_block<64, false>(tab, src + (uint64_t)b * in_stride, n,
                                                dst + (uint64_t)b * dst_stride, flags, lane);
     if (lane == 0)
@@ -1057,10 +1079,14 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
     uint32_t *__restrict__ scratch_gen, uint32_t *__restrict__ select, uint32_t auto_mode)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
+    __shared__ uint32_t dup_bm[(kGroupWaves - 1) * 512];  // one 16384-bit bitmap per global-table wave
     if (auto_mode && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
         return;
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
+    if (wave >= 1)
+        for (uint32_t i = lane; i < 512; i += 64)
+            dup_bm[(wave - 1) * 512u + i] = 0;
     const uint32_t my_slot = blockIdx.x * (kGroupWaves - 1) + (wave ? wave - 1 : 0);
     uint32_t *my_glob = scratch_tables + (size_t)my_slot * kMaxTable;
     uint32_t gen = 0;
@@ -1087,11 +1113,11 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
                     my_glob[i] = 0;
                 gen = 1;
             }
-            const HashTab<false> tab{nullptr, my_glob, gen << 16};
+            const HashTab<false> tab{nullptr, my_glob, gen << 16, dup_bm + (wave - 1) * 512u};
             op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
         } else {
-            const HashTab<true> tab{lds_tab, nullptr, 0u};
+            const HashTab<true> tab{lds_tab, nullptr, 0u, nullptr};
             op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
         }
