@@ -132,19 +132,26 @@ __device__ __forceinline__ uint32_t matchlen16(uint32_t a1, uint32_t a2, uint32_
     return m;
 }
 
-// Same over 32 bytes (second halves a2/b2); 4..32.
+// Same over 32 bytes (second halves a2/b2); 4..32.  Per dword: bit index of the first difference
+// (v_ffbl_b32 of 0 is 0xffffffff and the saturating add keeps it there); minimum over the dwords.
+__device__ __forceinline__ uint32_t diff_bit(uint32_t x, uint32_t y, uint32_t base)
+{
+    uint32_t f, r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(x ^ y));
+    asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(f), "v"(base));
+    return r;
+}
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t m = a < b ? a : b;
+    return m < c ? m : c;
+}
 __device__ __forceinline__ uint32_t matchlen32(const u32x4 &a, const u32x4 &a2, const u32x4 &b, const u32x4 &b2)
 {
-    uint32_t m = 32;
-    uint32_t d;
-    d = a2.w ^ b2.w; if (d) m = 28 + (__builtin_ctz(d) >> 3);
-    d = a2.z ^ b2.z; if (d) m = 24 + (__builtin_ctz(d) >> 3);
-    d = a2.y ^ b2.y; if (d) m = 20 + (__builtin_ctz(d) >> 3);
-    d = a2.x ^ b2.x; if (d) m = 16 + (__builtin_ctz(d) >> 3);
-    d = a.w ^ b.w; if (d) m = 12 + (__builtin_ctz(d) >> 3);
-    d = a.z ^ b.z; if (d) m = 8 + (__builtin_ctz(d) >> 3);
-    d = a.y ^ b.y; if (d) m = 4 + (__builtin_ctz(d) >> 3);
-    return m;
+    uint32_t m = umin3(diff_bit(a.y, b.y, 32), diff_bit(a.z, b.z, 64), diff_bit(a.w, b.w, 96));
+    m = umin3(m, diff_bit(a2.x, b2.x, 128), diff_bit(a2.y, b2.y, 160));
+    m = umin3(m, diff_bit(a2.z, b2.z, 192), diff_bit(a2.w, b2.w, 224));
+    return (m < 256u ? m : 256u) >> 3;
 }
 
 // Cooperative byte copy by one wave, dst-aligned 16-byte stores in the bulk; long copies stream
