@@ -116,6 +116,52 @@ __global__ __launch_bounds__(64) void k_shuf(const uint8_t* __restrict__ src, ui
   }
 }
 
+// contiguous tile per workgroup (the shape of a generic elementwise kernel): TPB threads, U x 16 B each
+template<int TPB, int U, int NT>
+__global__ __launch_bounds__(TPB) void k_tile(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t dstride){
+  const size_t tile = (size_t)TPB * U * 16;
+  const size_t off = (size_t)blockIdx.x * tile;          // byte offset in the input
+  const size_t blk = off >> 16, inb = off & 65535;       // 64 KiB block and offset inside it (tile <= 64 KiB, divides it)
+  const u32x4* s = (const u32x4*)(src + off);
+  u32x4* d = (u32x4*)(dst + blk * dstride + inb);
+  u32x4 q[U];
+  #pragma unroll
+  for (int u=0;u<U;u++) q[u] = NT ? __builtin_nontemporal_load(s + threadIdx.x + TPB*u) : s[threadIdx.x + TPB*u];
+  #pragma unroll
+  for (int u=0;u<U;u++) { if (NT) __builtin_nontemporal_store(q[u], d + threadIdx.x + TPB*u); else d[threadIdx.x + TPB*u] = q[u]; }
+}
+// wave per 64 KiB block without the LDS reservation (occupancy not limited to 4 waves per CU)
+template<int U, int NT>
+__global__ __launch_bounds__(64) void k_wave_nolds(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t dstride){
+  const uint32_t lane = threadIdx.x;
+  const u32x4* s = (const u32x4*)(src + (size_t)blockIdx.x*65536);
+  u32x4* d = (u32x4*)(dst + (size_t)blockIdx.x*dstride);
+  for (uint32_t i = lane; i < 4096; i += U*64){
+    u32x4 q[U];
+    #pragma unroll
+    for (int u=0;u<U;u++) q[u]= NT ? __builtin_nontemporal_load(s+i+64*u) : s[i+64*u];
+    #pragma unroll
+    for (int u=0;u<U;u++) { if (NT) __builtin_nontemporal_store(q[u], d+i+64*u); else d[i+64*u]=q[u]; }
+  }
+}
+
+// wave per 64 KiB block, whole block in flight (64 x 16 B per lane), chunk order rotated per block
+template<int ROT, int NT>
+__global__ __launch_bounds__(64) void k_wave_all(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t dstride){
+  __shared__ uint8_t pad[32768];
+  if (threadIdx.x==9999) pad[dstride&1023]=1;
+  const uint32_t lane = threadIdx.x;
+  const u32x4* s = (const u32x4*)(src + (size_t)blockIdx.x*65536);
+  u32x4* d = (u32x4*)(dst + (size_t)blockIdx.x*dstride);
+  const uint32_t rot = ROT ? (blockIdx.x * 7u) & 63u : 0u;
+  u32x4 q[64];
+  #pragma unroll
+  for (int u=0;u<64;u++) { const uint32_t c = (u + rot) & 63u; q[u] = NT ? __builtin_nontemporal_load(s+lane+64*c) : s[lane+64*c]; }
+  #pragma unroll
+  for (int u=0;u<64;u++) { const uint32_t c = (u + rot) & 63u; if (NT) __builtin_nontemporal_store(q[u], d+lane+64*c); else d[lane+64*c]=q[u]; }
+  if (threadIdx.x==9999) dst[0]=pad[5];
+}
+
 int main(int argc, char** argv){
   size_t nblk = argc>1 ? atol(argv[1]) : 32768;
   size_t dstride = 76544;
@@ -160,5 +206,21 @@ int main(int argc, char** argv){
 #define S(U,L,dl,name) timeit(name, [&]{ hipLaunchKernelGGL((k_shuf<U,L>), dim3(nblk), dim3(64), 0, 0, src, dst, (uint32_t)dl, (uint64_t)dstride); });
   S(8,32,10, "wave/blk shuffle-realign U=8  delta=10");
   S(16,32,10,"wave/blk shuffle-realign U=16 delta=10");
+#define T(TPB,U,NT,name) { size_t tile=(size_t)TPB*U*16; timeit(name, [&]{ hipLaunchKernelGGL((k_tile<TPB,U,NT>), dim3(nblk*65536/tile), dim3(TPB), 0, 0, src, dst, (uint64_t)dstride); }); }
+  T(256,1,0,"tile 4 KiB/WG 256thr plain");
+  T(256,4,0,"tile 16 KiB/WG 256thr plain");
+  T(256,4,1,"tile 16 KiB/WG 256thr nt");
+  T(256,16,1,"tile 64 KiB/WG 256thr nt");
+  T(512,4,0,"tile 32 KiB/WG 512thr plain");
+  T(1024,4,0,"tile 64 KiB/WG 1024thr plain");
+  T(1024,4,1,"tile 64 KiB/WG 1024thr nt");
+  T(64,4,0,"tile 4 KiB/WG 64thr plain");
+  T(64,4,1,"tile 4 KiB/WG 64thr nt");
+  timeit("wave/blk no LDS U=4 plain", [&]{ hipLaunchKernelGGL((k_wave_nolds<4,0>), dim3(nblk), dim3(64), 0, 0, src, dst, (uint64_t)dstride); });
+  timeit("wave/blk no LDS U=4 nt", [&]{ hipLaunchKernelGGL((k_wave_nolds<4,1>), dim3(nblk), dim3(64), 0, 0, src, dst, (uint64_t)dstride); });
+  timeit("wave/blk no LDS U=16 nt", [&]{ hipLaunchKernelGGL((k_wave_nolds<16,1>), dim3(nblk), dim3(64), 0, 0, src, dst, (uint64_t)dstride); });
+  timeit("wave/blk whole block in regs nt", [&]{ hipLaunchKernelGGL((k_wave_all<0,1>), dim3(nblk), dim3(64), 0, 0, src, dst, (uint64_t)dstride); });
+  timeit("wave/blk whole block in regs nt, rotated", [&]{ hipLaunchKernelGGL((k_wave_all<1,1>), dim3(nblk), dim3(64), 0, 0, src, dst, (uint64_t)dstride); });
+  timeit("wave/blk whole block in regs plain, rotated", [&]{ hipLaunchKernelGGL((k_wave_all<1,0>), dim3(nblk), dim3(64), 0, 0, src, dst, (uint64_t)dstride); });
   return 0;
 }
