@@ -990,8 +990,8 @@ __device__ __forceinline__ uint32_t block_length(const uint32_t *__restrict__ in
 }
 
 // ---- kernel selection by sampled compressibility (auto mode)
-// The dual kernel wins on compressible data (two waves per SIMD hide each other's instruction
-// latency: text +30%, low-entropy +37%), the single kernel on incompressible data (whole block in
+// The multi-wave ("dual") kernel wins on compressible data (three waves per SIMD fill each other's
+// issue slots: text +65%, low-entropy +67%), the single kernel on incompressible data (whole block in
 // registers, no slow global-table wave: +7%).  A tiny sampling kernel looks at the first 1 KiB of up
 // to 64 evenly spaced blocks and counts 4-byte shingles seen before (16-bit hash into an LDS
 // bitmap); both kernels are launched and the one not chosen exits at once.  Either kernel produces
@@ -1070,9 +1070,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // its table in LDS; the others have generation-tagged tables in global memory (one slot each in
 // `scratch`).  Persistent grid: all waves pull block indices from one device-wide counter (zeroed
 // by a tiny kernel ahead of the launch), so the faster (LDS-table) waves take more of them and
-// mixed workloads balance.  Measured on 64 KiB text blocks: 2 waves 42 GB/s, 3 waves 48, 4 waves 44
-// (register spills); one wave per SIMD (single kernel) 32.  With 3 waves a wave has 170 registers,
-// so no part of the block is kept in registers (incompressible data goes to the single kernel).
+// mixed workloads balance.  Measured on 64 KiB text blocks: 2 waves 42 GB/s, 3 waves 53, 4 waves 45,
+// 5 waves 42 (with three the SIMDs already have an instruction in flight 95 % of the time; more
+// waves only add L2 misses on the global tables); one wave per SIMD (single kernel) 32.  The block
+// is not kept in registers here (incompressible data goes to the single kernel).
 #ifndef SZ_GROUP_WAVES
 #define SZ_GROUP_WAVES 3  // waves per workgroup = waves per SIMD (one LDS-table wave + global-table waves)
 #endif
@@ -1442,7 +1443,7 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
         hipLaunchKernelGGL(compress_blocks_kernel, dim3(n_blocks), dim3(64), 0, stream, src, in_stride, d_in_len,
                            total_len, n_blocks, dst, dst_stride, d_out_len, flags, select);
     if (dual_ok) {
-        // enough blocks to keep two waves per SIMD busy on every CU: persistent dual-wave grid
+        // enough blocks to keep kGroupWaves waves per SIMD busy on every CU: persistent grid
         uint32_t grid = (n_blocks + kGroupWaves - 1) / kGroupWaves;
         grid = grid < dual->n_slots ? grid : dual->n_slots;
         hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(64 * kGroupWaves), 0, stream, src, in_stride,
