@@ -1264,24 +1264,26 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             olen_v = l6 + 1;
             aux_v = extra;
         }
-        // ---- which lanes start an element?  (scalar walk; literal sizes are validated here)
+        // ---- which lanes start an element?  Every lane knows where an element starting at it would
+        // end (64 = outside the window, also for a literal that cannot be valid); the serial part is
+        // one v_readlane per element.
+        const bool bad_v = kind_v == 0 && (olen_v == 0 || (uint64_t)ip + lane + aux_v + olen_v > n);
+        const uint64_t end_v = (uint64_t)lane + (kind_v == 0 ? (uint64_t)aux_v + olen_v : (uint64_t)size_v);
+        const uint32_t nx_v = (bad_v || end_v > 64) ? 64u : (uint32_t)end_v;
         uint64_t Pm = 0;
         uint32_t j = 0;
-        while (j < 64) {
+        do {
             Pm |= 1ull << j;
-            if (lane_get(kind_v, j) == 0) {
-                const uint32_t len = lane_get(olen_v, j), hdr = lane_get(aux_v, j);
-                if (len == 0 || (uint64_t)ip + j + hdr + len > n) {
-                    st = kStatusCorrupt;
-                    break;
-                }
-                j += hdr + len;
-            } else {
-                j += lane_get(size_v, j);
-            }
-        }
-        if (st != 0)
+            j = lane_get(nx_v, j);
+        } while (j < 64);
+        if (__ballot(bad_v) & Pm) {
+            st = kStatusCorrupt;
             break;
+        }
+        {   // the last element may reach past the window: the next window starts where it really ends
+            const uint32_t e_last = 63u - (uint32_t)__builtin_clzll(Pm);
+            j = e_last + lane_get(size_v, e_last);  // (sizes of valid elements fit: n < 2^31)
+        }
         // ---- output offsets of the window's elements
         const bool is_elem = (Pm >> lane) & 1;
         const uint32_t olen = is_elem ? olen_v : 0u;
@@ -1309,27 +1311,36 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             const uint8_t *sp = small_lit ? in + ip + lane + aux_v : out + op + o_rel - aux_v;
             uint8_t *dp = out + op + o_rel;
             const uint32_t mylen = par ? olen : 0u;
-            // longest parallel element (wave max through the ballots of its bits; lengths <= 64)
-            uint32_t maxlen = 0;
-            for (int bit = 6; bit >= 0; bit--)
-                if (__ballot(mylen >= (maxlen | (1u << bit))) != 0)
-                    maxlen |= 1u << bit;
-            for (uint32_t i = 0; i < maxlen; i += 16) {
-                uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-                if (i + 4 <= mylen) w0 = ld32(sp + i);
-                if (i + 8 <= mylen) w1 = ld32(sp + i + 4);
-                if (i + 12 <= mylen) w2 = ld32(sp + i + 8);
-                if (i + 16 <= mylen) w3 = ld32(sp + i + 12);
-                if (i + 4 <= mylen) __builtin_memcpy(dp + i, &w0, 4);
-                if (i + 8 <= mylen) __builtin_memcpy(dp + i + 4, &w1, 4);
-                if (i + 12 <= mylen) __builtin_memcpy(dp + i + 8, &w2, 4);
-                if (i + 16 <= mylen) __builtin_memcpy(dp + i + 12, &w3, 4);
+            // 16 bytes per step while any element has that many left, then 8, 4 and up to 3 single
+            // bytes: few predicated memory instructions for the short elements that dominate.
+            // (sources and destinations of different lanes never overlap: far copies end before the
+            // window's output begins, literals come from the input)
+            uint32_t i = 0;
+            while (__ballot(i + 16 <= mylen) != 0) {
+                if (i + 16 <= mylen) {
+                    const u32x4 v = ld128(sp + i);
+                    __builtin_memcpy(dp + i, &v, 16);
+                    i += 16;
+                }
             }
-            // tails: up to 3 bytes per element
-            const uint32_t tail0 = mylen & ~3u;
-            for (uint32_t k = 0; k < 3; k++)
-                if (tail0 + k < mylen)
-                    dp[tail0 + k] = sp[tail0 + k];
+            if (mylen & 8u) {
+                const uint64_t v = ld64(sp + i);
+                __builtin_memcpy(dp + i, &v, 8);
+                i += 8;
+            }
+            if (mylen & 4u) {
+                const uint32_t v = ld32(sp + i);
+                __builtin_memcpy(dp + i, &v, 4);
+                i += 4;
+            }
+            if (mylen & 2u) {
+                uint16_t v;
+                __builtin_memcpy(&v, sp + i, 2);
+                __builtin_memcpy(dp + i, &v, 2);
+                i += 2;
+            }
+            if (mylen & 1u)
+                dp[i] = sp[i];
         }
         // literals longer than 64 bytes: cooperative copies (their data comes from the input)
         for (uint64_t B = __ballot(big_lit); B; B &= B - 1) {
@@ -1340,8 +1351,10 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
         for (uint64_t N = __ballot(near_copy); N; N &= N - 1) {
             const uint32_t e = ctz64(N);
             const uint32_t len = lane_get(olen_v, e), off = lane_get(aux_v, e), o = op + lane_get(o_rel, e);
+            // (off >= len: plain copy; else the last `off` bytes repeat -- the division only then)
+            const uint32_t k = off >= len ? lane : lane % off;
             if (lane < len)
-                out[o + lane] = out[o - off + (lane % off)];
+                out[o + lane] = out[o - off + k];
         }
         op += total;
         if (st != 0)
@@ -1405,8 +1418,9 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             }
             // len <= 64: one byte per lane; an overlapping copy (off < len) repeats the last off
             // bytes, so lane i reads byte (i mod off) of the window [op-off, op).
+            const uint32_t k = off >= len ? lane : lane % off;
             if (lane < len)
-                out[op + lane] = out[op - off + (lane % off)];
+                out[op + lane] = out[op - off + k];
             ip += hdr;
             op += len;
         }
