@@ -155,8 +155,8 @@ __device__ __forceinline__ uint32_t matchlen32(const u32x4 &a, const u32x4 &a2, 
 }
 
 // Cooperative byte copy by one wave, dst-aligned 16-byte stores in the bulk; long copies stream
-// with non-temporal loads/stores, 16 KiB in flight.
-template <bool kDeep = true>
+// with non-temporal loads/stores, kDepth KiB in flight (0: none; the depth costs 4 VGPRs per KiB).
+template <int kDepth = 16>
 __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s,
                                           uint32_t len, uint32_t lane)
 {
@@ -173,14 +173,14 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t
     len -= head;
     const uint32_t nvec = len >> 4;
     uint32_t i = lane;
-    if (kDeep && nvec >= 1024) {
-        for (; i + 960 < nvec; i += 1024) {
-            u32x4 q[16];
+    if (kDepth > 0 && nvec >= 64u * kDepth) {
+        for (; i + 64u * (kDepth - 1) < nvec; i += 64u * kDepth) {
+            u32x4 q[kDepth > 0 ? kDepth : 1];
 #pragma unroll
-            for (int u = 0; u < 16; u++)
+            for (int u = 0; u < kDepth; u++)
                 q[u] = ld128_nt(s + 16 * (size_t)(i + 64 * u));
 #pragma unroll
-            for (int u = 0; u < 16; u++)
+            for (int u = 0; u < kDepth; u++)
                 __builtin_nontemporal_store(q[u], reinterpret_cast<u32x4 *>(d + 16 * (size_t)(i + 64 * u)));
         }
     }
@@ -203,7 +203,7 @@ __device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t
 
 // Literal element (a7): tag (len-1)<<2 for len<=60 (CompressionAccelerator.scala:172,231-233);
 // software Snappy tags 60/61 + 1/2 little-endian bytes of len-1 for longer runs (len<=65536).
-template <bool kDeep = true>
+template <int kDepth = 16>
 __device__ __forceinline__ uint32_t emit_literal(uint8_t *__restrict__ out, uint32_t op,
                                                  const uint8_t *__restrict__ s, uint32_t len,
                                                  uint32_t lane)
@@ -222,7 +222,7 @@ __device__ __forceinline__ uint32_t emit_literal(uint8_t *__restrict__ out, uint
     }
     if (lane < hdr)
         out[op + lane] = (uint8_t)(word >> (8 * lane));
-    wave_copy<kDeep>(out + op + hdr, s, len, lane);
+    wave_copy<kDepth>(out + op + hdr, s, len, lane);
     return op + hdr + len;
 }
 
@@ -523,7 +523,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 big_len = len;
                 op += 3 + len;
             } else {
-                op = emit_literal<!kLean>(out, op, in + from, len, lane);
+                op = emit_literal<(kLean ? 0 : 16)>(out, op, in + from, len, lane);
             }
         };
 
@@ -970,7 +970,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         }
     }
     if (next_emit < n)  // blocks shorter than the 15-byte margin are one literal
-        op = emit_literal<!kLean>(out, op, in + next_emit, n - next_emit, lane);
+        op = emit_literal<(kLean ? 0 : 16)>(out, op, in + next_emit, n - next_emit, lane);
     return poisoned ? 0xfffffffeu : op;
 }
 
@@ -1345,7 +1345,7 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
         // literals longer than 64 bytes: cooperative copies (their data comes from the input)
         for (uint64_t B = __ballot(big_lit); B; B &= B - 1) {
             const uint32_t e = ctz64(B);
-            wave_copy(out + op + lane_get(o_rel, e), in + ip + e + lane_get(aux_v, e), lane_get(olen_v, e), lane);
+            wave_copy<6>(out + op + lane_get(o_rel, e), in + ip + e + lane_get(aux_v, e), lane_get(olen_v, e), lane);
         }
         // near copies, in stream order (they may read what the steps above and each other wrote)
         for (uint64_t N = __ballot(near_copy); N; N &= N - 1) {
@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
                 st = kStatusCorrupt;
                 break;
             }
-            wave_copy(out + op, in + ip + hdr, len, lane);
+            wave_copy<6>(out + op, in + ip + hdr, len, lane);
             ip += hdr + len;
             op += len;
         } else {
