@@ -1,0 +1,14 @@
+# Refreshes the committed evidence under profiles/ (run on the GPU box through gpurun).
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_final
+rm -rf $O; mkdir -p $O
+timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o c3 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --no-extra > $O/c3.log 2>&1 || echo "c3 stats failed"
+echo "c3 stats done"
+timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $O/text -o text -- python3 $R/tools/quickbench.py text 16384 5 > $O/text.log 2>&1 || echo "text stats failed"
+echo "text stats done"
+for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  timeout -k 10 250 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$tag -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extra > $O/pmc_$tag.log 2>&1 || echo "pmc $tag failed"
+  echo "pmc $tag done"
+done
