@@ -1265,17 +1265,22 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             aux_v = extra;
         }
         // ---- which lanes start an element?  Every lane knows where an element starting at it would
-        // end (64 = outside the window, also for a literal that cannot be valid); the serial part is
-        // one v_readlane per element.
+        // end (63 = outside the window, also for a literal that cannot be valid: lane 63 never starts
+        // an element of this window, so it can stand for "out" and absorb the walk); the serial part
+        // is one v_readlane per element.
         const bool bad_v = kind_v == 0 && (olen_v == 0 || (uint64_t)ip + lane + aux_v + olen_v > n);
         const uint64_t end_v = (uint64_t)lane + (kind_v == 0 ? (uint64_t)aux_v + olen_v : (uint64_t)size_v);
-        const uint32_t nx_v = (bad_v || end_v > 64) ? 64u : (uint32_t)end_v;
+        const uint32_t nx_v = (bad_v || end_v > 62 || lane == 63) ? 63u : (uint32_t)end_v;
         uint64_t Pm = 0;
         uint32_t j = 0;
         do {
-            Pm |= 1ull << j;
-            j = lane_get(nx_v, j);
-        } while (j < 64);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                Pm |= 1ull << j;
+                j = lane_get(nx_v, j);
+            }
+        } while (j != 63);
+        Pm &= ~(1ull << 63);
         if (__ballot(bad_v) & Pm) {
             st = kStatusCorrupt;
             break;
