@@ -1244,26 +1244,17 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
         const uint32_t extra = (uint32_t)(x >> 8);
         const uint32_t kind_v = tag & 3u;
         const uint32_t l6 = tag >> 2;
-        uint32_t size_v, olen_v, aux_v;  // compressed size, produced bytes, (literal: header bytes | copy: offset)
-        if (kind_v == 0) {
-            const uint32_t nb = l6 < 60 ? 0u : l6 - 59u;
-            const uint32_t lenm1 = nb == 0 ? l6 : (nb == 4 ? extra : (extra & ((1u << (8 * nb)) - 1u)));
-            aux_v = 1 + nb;
-            olen_v = lenm1 + 1;        // wraps to 0 for 2^32: rejected below
-            size_v = aux_v + olen_v;   // may wrap for absurd lengths: the bound checks use 64 bits
-        } else if (kind_v == 1) {
-            size_v = 2;
-            olen_v = (l6 & 7u) + 4;
-            aux_v = ((tag >> 5) << 8) | (extra & 0xffu);
-        } else if (kind_v == 2) {
-            size_v = 3;
-            olen_v = l6 + 1;
-            aux_v = extra & 0xffffu;
-        } else {
-            size_v = 5;
-            olen_v = l6 + 1;
-            aux_v = extra;
-        }
+        // compressed size, produced bytes, (literal: header bytes | copy: offset) -- selects, no branches
+        const bool is_lit_v = kind_v == 0;
+        const uint32_t nb = (is_lit_v && l6 >= 60) ? l6 - 59u : 0u;                  // literal: length bytes
+        const uint32_t lenm1 = nb == 0 ? l6 : (extra & (0xffffffffu >> (32u - 8u * nb)));
+        const uint32_t c_off = kind_v == 1 ? (((tag >> 5) << 8) | (extra & 0xffu))
+                                           : (kind_v == 2 ? (extra & 0xffffu) : extra);
+        const uint32_t aux_v = is_lit_v ? 1u + nb : c_off;
+        const uint32_t olen_v = is_lit_v ? lenm1 + 1u                                  // wraps to 0 for 2^32: rejected below
+                                         : (kind_v == 1 ? (l6 & 7u) + 4u : l6 + 1u);
+        const uint32_t size_v = is_lit_v ? aux_v + olen_v                              // may wrap: the bound checks use 64 bits
+                                         : (kind_v == 1 ? 2u : (kind_v == 2 ? 3u : 5u));
         // ---- which lanes start an element?  Every lane knows where an element starting at it would
         // end (63 = outside the window, also for a literal that cannot be valid: lane 63 never starts
         // an element of this window, so it can stand for "out" and absorb the walk); the serial part
@@ -1328,24 +1319,20 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
                     i += 16;
                 }
             }
-            if (mylen & 8u) {
-                const uint64_t v = ld64(sp + i);
-                __builtin_memcpy(dp + i, &v, 8);
-                i += 8;
-            }
-            if (mylen & 4u) {
-                const uint32_t v = ld32(sp + i);
-                __builtin_memcpy(dp + i, &v, 4);
-                i += 4;
-            }
-            if (mylen & 2u) {
-                uint16_t v;
-                __builtin_memcpy(&v, sp + i, 2);
-                __builtin_memcpy(dp + i, &v, 2);
-                i += 2;
-            }
-            if (mylen & 1u)
-                dp[i] = sp[i];
+            // the 8/4/2/1-byte pieces: all loads, then all stores (one memory latency, not four)
+            const uint32_t i8 = i, i4 = i8 + (mylen & 8u), i2 = i4 + (mylen & 4u), i1 = i2 + (mylen & 2u);
+            uint64_t v8 = 0;
+            uint32_t v4 = 0;
+            uint16_t v2 = 0;
+            uint8_t v1 = 0;
+            if (mylen & 8u) v8 = ld64(sp + i8);
+            if (mylen & 4u) v4 = ld32(sp + i4);
+            if (mylen & 2u) __builtin_memcpy(&v2, sp + i2, 2);
+            if (mylen & 1u) v1 = sp[i1];
+            if (mylen & 8u) __builtin_memcpy(dp + i8, &v8, 8);
+            if (mylen & 4u) __builtin_memcpy(dp + i4, &v4, 4);
+            if (mylen & 2u) __builtin_memcpy(dp + i2, &v2, 2);
+            if (mylen & 1u) dp[i1] = v1;
         }
         // literals longer than 64 bytes: cooperative copies (their data comes from the input)
         for (uint64_t B = __ballot(big_lit); B; B &= B - 1) {
