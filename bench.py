@@ -72,28 +72,48 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
 
     src = make_input(kind, first_block, n_blocks, device)
     dst = torch.empty(n_blocks * P.SLOT_STRIDE, dtype=torch.uint8, device=device)
-    out_len = torch.zeros(n_blocks, dtype=torch.int32, device=device)
     world = dist.get_world_size() if dist_on else 1
+    n_total = n_blocks * world
+    # Two sets of length buffers: the all_gather + scan of step i run on a side stream under the
+    # compression of step i+1 (the collective is latency-bound: 128 KiB per rank).
+    out_lens = [torch.zeros(n_blocks, dtype=torch.int32, device=device) for _ in range(2)]
+    out_len = out_lens[0]
+    if dist_on:
+        comm = torch.cuda.Stream(device)
+        gathered = [torch.empty(n_total, dtype=torch.int32, device=device) for _ in range(2)]
+        offs = [torch.empty(n_total + 1, dtype=torch.int64, device=device) for _ in range(2)]
+    consumed = [None, None]
 
-    def step():
-        P.compress_blocks(src, BLOCK, n_blocks, dst=dst, out_len=out_len, varint=True)
+    def step(i, e0=None, e1=None):
+        k = i & 1
+        main = torch.cuda.current_stream()
+        if consumed[k] is not None:
+            main.wait_event(consumed[k])  # the gather of step i-2 has read out_lens[k]
+        if e0 is not None:
+            e0.record()  # same stream as the kernel launch (torch's current stream)
+        P.compress_blocks(src, BLOCK, n_blocks, dst=dst, out_len=out_lens[k], varint=True)
+        if e1 is not None:
+            e1.record()
         if dist_on:
-            shard.gather_lengths(out_len, n_blocks * world)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                shard.gather_lengths(out_lens[k], n_total, out=gathered[k], offsets=offs[k])
+                consumed[k] = torch.cuda.Event()
+                consumed[k].record(comm)
 
-    for _ in range(warmup):
-        step()
+    for i in range(warmup):
+        step(i)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        ev[i][0].record()  # same stream as the kernel launch (torch's current stream)
-        P.compress_blocks(src, BLOCK, n_blocks, dst=dst, out_len=out_len, varint=True)
-        ev[i][1].record()
-        if dist_on:
-            shard.gather_lengths(out_len, n_blocks * world)
-    torch.cuda.synchronize()
+        step(warmup + i, ev[i][0], ev[i][1])
+    torch.cuda.synchronize()  # all streams of the device: the last gather too
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -102,6 +122,9 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the gathered layout is what every rank would pack with: same on all ranks, ends at the total
+        assert int(offs[(warmup + steps - 1) & 1][-1].item()) == int(gathered[(warmup + steps - 1) & 1].sum().item())
+    out_len = out_lens[(warmup + steps - 1) & 1] if steps + warmup > 0 else out_lens[0]
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
     # ---- checks, outside the timed region: sample blocks against the oracle, all lengths sane
@@ -209,6 +232,8 @@ def main():
     ap.add_argument("--blocks-per-gpu", type=int, default=32768)
     ap.add_argument("--no-extra", action="store_true", help="skip the short text/c5/mix passes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl = RCCL) even with one rank: rehearsal of the N>1 path")
     args = ap.parse_args()
 
     import torch
@@ -223,7 +248,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist_on = world > 1
+    dist_on = world > 1 or args.force_dist  # (--force-dist: rehearse the RCCL path with a single rank)
     if dist_on:
         dist.init_process_group("nccl", device_id=device)
     if args.gpus != world and rank == 0:

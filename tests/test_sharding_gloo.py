@@ -38,6 +38,13 @@ def _worker(rank, world, port, n_total, q):
     b, e = sharding.shard_range(n_total, rank, world)
     lens = torch.tensor([len(oracle_lib.raw_compress(x)) for x in _blocks(n_total)[b:e]], dtype=torch.int32)
     all_lens, offs = sharding.gather_lengths(lens, n_total)
+    # steady-state form (bench.py): preallocated results, reused every step
+    out = torch.full((n_total,), -1, dtype=torch.int32)
+    off2 = torch.full((n_total + 1,), -1, dtype=torch.int64)
+    for _ in range(2):
+        a2, o2 = sharding.gather_lengths(lens, n_total, out=out, offsets=off2)
+        assert a2.data_ptr() == out.data_ptr() and o2.data_ptr() == off2.data_ptr()
+        assert torch.equal(a2, all_lens) and torch.equal(o2, offs)
     q.put((rank, all_lens.numpy().tolist(), offs.numpy().tolist()))
     dist.barrier()
     dist.destroy_process_group()
