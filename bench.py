@@ -122,8 +122,14 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the gathered layout is what every rank would pack with: same on all ranks, ends at the total
-        assert int(offs[(warmup + steps - 1) & 1][-1].item()) == int(gathered[(warmup + steps - 1) & 1].sum().item())
+        # the gathered layout is what every rank would pack with: ends at the total, and this rank's
+        # slice of it is this rank's own lengths (reported, not asserted: a bench line beats a traceback)
+        kk = (warmup + steps - 1) & 1
+        r = dist.get_rank()
+        layout_ok = (int(offs[kk][-1].item()) == int(gathered[kk].sum().item())
+                     and bool(torch.equal(gathered[kk][r * n_blocks:(r + 1) * n_blocks], out_lens[kk])))
+    else:
+        layout_ok = None
     out_len = out_lens[(warmup + steps - 1) & 1] if steps + warmup > 0 else out_lens[0]
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
@@ -152,7 +158,7 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
         del back
     del src, dst
     return {"elapsed_s": elapsed, "kernel_ms": kernel_ms, "in_bytes": n_blocks * BLOCK, "out_bytes": out_bytes,
-            "bit_exact_sample": bool(exact), "n_blocks": n_blocks, "decompress": dec}
+            "bit_exact_sample": bool(exact), "n_blocks": n_blocks, "decompress": dec, "gathered_layout_ok": layout_ok}
 
 
 def cpu_baseline(kind, sample_blocks, budget_s=12.0):
@@ -313,6 +319,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes},
             "workloads": extras,
         }
+        if main_res.get("gathered_layout_ok") is not None:
+            line["gathered_layout_ok"] = main_res["gathered_layout_ok"]  # rank 0's view of the all_gather result
         if not args.no_cpu and world == 1:  # host baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.workload, 1024)
             if "text" in extras:  # the same oracle on the latency-bound workload, for scale (bounded: ~4 s)
