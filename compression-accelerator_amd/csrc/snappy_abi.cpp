@@ -341,6 +341,8 @@ int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *ou
     uint64_t total = 0;
     SZ_HIP(hipMemcpyAsync(&total, d_off + nb, sizeof(total), hipMemcpyDeviceToHost, ws.stream));
     SZ_HIP(hipStreamSynchronize(ws.stream));
+    if (total == ~0ull)  // a fragment came back with an error marker instead of a length
+        return SZ_EHIP;
     if (total > dst_cap)
         return SZ_ENOSPC;
     SZ_HIP(hipMemcpyAsync(static_cast<uint8_t *>(dst) + nh, d_packed + nh, total - nh,

@@ -1140,16 +1140,29 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
 
 // Exclusive prefix sum of n lengths (+base) by one 1024-thread workgroup.
 __global__ __launch_bounds__(1024) void scan_lengths_kernel(const uint32_t *__restrict__ len, uint32_t n,
-                                                            uint64_t base, uint64_t *__restrict__ off)
+                                                            uint64_t base, uint64_t max_len,
+                                                            uint64_t *__restrict__ off)
 {
     __shared__ uint64_t part[1024];
+    __shared__ uint32_t bad;
     const uint32_t t = threadIdx.x;
+    if (t == 0)
+        bad = 0;
+    __syncthreads();
     const uint32_t per = (n + 1023) / 1024;
     const uint32_t lo = t * per < n ? t * per : n;
     const uint32_t hi = lo + per < n ? lo + per : n;
+    // a length above the slot size is one of the compress kernels' error markers (0xffffffff: block
+    // longer than 64 KiB, 0xfffffffe: internal): it counts as 0 and the total becomes UINT64_MAX
     uint64_t s = 0;
-    for (uint32_t i = lo; i < hi; i++)
-        s += len[i];
+    bool any_bad = false;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = len[i];
+        any_bad |= v > max_len;
+        s += v > max_len ? 0u : v;
+    }
+    if (any_bad)
+        atomicOr(&bad, 1u);
     part[t] = s;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
@@ -1160,11 +1173,12 @@ __global__ __launch_bounds__(1024) void scan_lengths_kernel(const uint32_t *__re
     }
     uint64_t run = base + (t ? part[t - 1] : 0);
     for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = len[i];
         off[i] = run;
-        run += len[i];
+        run += v > max_len ? 0u : v;
     }
     if (t == 1023)
-        off[n] = base + part[1023];
+        off[n] = bad ? ~0ull : base + part[1023];
 }
 
 __global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__restrict__ slots,
@@ -1177,6 +1191,8 @@ __global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__rest
     const uint8_t *s = slots + (uint64_t)b * slot_stride;
     uint8_t *d = packed + off[b];
     uint32_t n = len[b];
+    if (n > slot_stride)  // error marker: nothing to move (the scan reports it)
+        return;
     uint32_t head = (16u - (uint32_t)((uintptr_t)d & 15u)) & 15u;
     if (head > n)
         head = n;
@@ -1482,7 +1498,7 @@ hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const u
                               uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
                               hipStream_t stream)
 {
-    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, stream, d_len, n_blocks, base, d_off);
+    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, stream, d_len, n_blocks, base, slot_stride, d_off);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || n_blocks == 0)
         return e;

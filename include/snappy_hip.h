@@ -88,7 +88,9 @@ int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t sl
 /* Exclusive prefix sum of d_len[0..n_blocks) + base into d_off[0..n_blocks], d_off[n_blocks] =
  * total; then gathers slot b (d_slots + b*slot_stride, d_len[b] bytes) to d_packed + d_off[b].
  * With base = size of the stream's varint preamble this yields the body of snappy::Compress.
- * d_off must hold n_blocks+1 uint64. */
+ * d_off must hold n_blocks+1 uint64.  A d_len[b] above slot_stride (the compress kernels mark a
+ * block they could not take with 0xffffffff) packs nothing for that slot and makes
+ * d_off[n_blocks] = UINT64_MAX. */
 int sz_pack_stream_hip(const void *d_slots, size_t slot_stride, const uint32_t *d_len,
                        uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
                        void *stream);

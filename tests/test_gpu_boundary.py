@@ -435,3 +435,26 @@ def test_two_streams_in_flight_at_once():
                 assert dn[int(b), :int(ln[b])].cpu().numpy().tobytes() == oracle_lib.raw_compress(blk), int(b)
         # every block of every launch: same lengths as the first launch on that stream
         assert torch.equal(la, outs[0][1]) and torch.equal(lb, outs[0][3])
+
+
+def test_pack_reports_error_markers_instead_of_following_them():
+    """A block the compress kernel refused (in_len > 64 KiB -> out_len 0xffffffff) must not turn into a
+    4 GiB gather: the pack step skips it and flags the total."""
+    import torch
+    P = pkg()
+    nb = 6
+    blocks = [fuzzgen.gen("text_mtg", 900 + i, 65536).tobytes() for i in range(nb)]
+    src = torch.from_numpy(np.frombuffer(b"".join(blocks), dtype=np.uint8).copy()).cuda()
+    in_len = torch.tensor([65536, 65536, 70000, 65536, 0, 65536], dtype=torch.int32, device="cuda")
+    slots, lens = P.compress_blocks(src, 65536, nb, in_len=in_len, varint=False)
+    torch.cuda.synchronize()
+    ln = lens.cpu().numpy().astype(np.uint32)
+    assert ln[2] == 0xffffffff and ln[4] == 0
+    packed, offs = P.pack_stream(slots, P.SLOT_STRIDE, lens, nb, base=3)
+    torch.cuda.synchronize()
+    o = offs.cpu().numpy().astype(np.uint64)
+    assert o[nb] == np.uint64(0xffffffffffffffff)
+    # the good blocks are still packed back to back (the refused one counts as empty)
+    assert o[0] == 3 and o[1] == 3 + ln[0] and o[2] == o[1] + ln[1] and o[3] == o[2] and o[4] == o[3] + ln[3]
+    body0 = packed[3:3 + int(ln[0])].cpu().numpy().tobytes()
+    assert body0 == oracle_lib.raw_compress(blocks[0])[3:]
