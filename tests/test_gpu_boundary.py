@@ -253,6 +253,41 @@ def test_full_size_text_and_low_entropy():
     _full_size_round_trip("mix", 3072)
 
 
+def test_full_size_c4_per_gpu_share_mix_and_checksum_of_checksums():
+    """BASELINE.json configs[3]: one GPU's share of the 16 GiB run = 32 768 blocks (2 GiB) of the
+    c3/text/c5 mix.  Round trip of every block, sampled blocks == oracle, and a size-independent
+    property: the multiset of compressed blocks depends only on the blocks, so two halves compressed
+    in separate launches give the same per-block lengths and the same checksum of checksums as one
+    launch over everything."""
+    import torch
+    lens = _full_size_round_trip("mix", 32768)
+    import bench
+    P = pkg()
+    dev = torch.device("cuda:0")
+
+    def digest(first, count):
+        src = bench.make_input("mix", first, count, dev)
+        dst, ol = P.compress_blocks(src, 65536, count)
+        torch.cuda.synchronize()
+        d = dst.reshape(count, P.SLOT_STRIDE)
+        # per-block checksum on the GPU: sum of (byte * (position + 1)) over the used bytes, mod 2^61-1-ish in int64
+        pos = torch.arange(1, P.SLOT_STRIDE + 1, device=dev, dtype=torch.int64)
+        used = pos[None, :] <= ol[:, None].to(torch.int64)
+        cs = torch.zeros(count, dtype=torch.int64, device=dev)
+        for c0 in range(0, count, 2048):  # bounded temporaries
+            sl = slice(c0, min(count, c0 + 2048))
+            cs[sl] = ((d[sl].to(torch.int64) * pos[None, :]) * used[sl]).sum(dim=1)
+        return ol.cpu().numpy(), cs.cpu().numpy()
+
+    la, ca = digest(0, 8192)
+    lb, cb = digest(8192, 8192)
+    lw, cw = digest(0, 16384)
+    assert np.array_equal(np.concatenate([la, lb]), lw)
+    assert np.array_equal(np.concatenate([ca, cb]), cw)
+    assert np.array_equal(lw, lens[:16384])
+    assert int(np.bitwise_xor.reduce(cw)) == int(np.bitwise_xor.reduce(np.concatenate([ca, cb])))
+
+
 def test_all_mtg_cards_48_blocks_bit_exact():
     # BASELINE.json configs[1]
     mtg = fuzzgen.corpus("mtg")
