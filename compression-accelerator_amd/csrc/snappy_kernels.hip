@@ -332,6 +332,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
     return x;
 }
 
+__device__ __forceinline__ uint64_t below63(uint32_t k) { return (1ull << k) - 1; }  // bits 0..k-1, k <= 63
 __device__ __forceinline__ uint64_t lanes_below(uint32_t k)  // bits 0..k-1, k in 0..64
 {
     return k >= 64 ? ~0ull : ((1ull << k) - 1);
@@ -599,7 +600,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 uint32_t j, s, long_lane, lit_lane, new_scan_base;
                 bool ch, to_strided;
                 for (;;) {
-                    const uint64_t Hm = Hm_all & lanes_below(lim);
+                    const uint64_t Hm = Hm_all & below63(lim);  // lim <= 63
                     V = 0;
                     Hp = 0;
                     Ins = 0;
@@ -613,7 +614,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     // Can a scan of this window reach probe 32 (where the step becomes 2)?  Only through
                     // 32 misses in a row: a run of 32 hit-free lanes, or the misses carried in plus those
                     // before the first hit.  Almost never in compressible data -> lean walk.
-                    const uint64_t range = lanes_below(lim) & ~(uint64_t)first;
+                    const uint64_t range = below63(lim) & ~(uint64_t)first;
                     uint64_t z = ~Hm & range;
                     z &= z >> 1;
                     z &= z >> 2;
@@ -803,9 +804,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hp);
                     if (!entry_chain)  // a literal was open on entry (it began before W0): it ends at the first hit
                         emit_lit(entry_emit, W0 + jfirst - entry_emit);
-                    uint64_t Lit = V & ~Hp & lanes_below(jlast);
+                    uint64_t Lit = V & ~Hp & below63(jlast);
                     if (!entry_chain)
-                        Lit &= ~lanes_below(jfirst);
+                        Lit &= ~below63(jfirst);
                     const bool is_lit = (Lit >> lane) & 1;
                     const bool is_hit = (Hp >> lane) & 1;
                     const bool run_start = is_lit && !((lane > 0) && ((Lit >> (lane - 1)) & 1));
