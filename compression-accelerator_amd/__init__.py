@@ -29,7 +29,7 @@ ROCC_CHANNEL, ROCC_COMPRESS, ROCC_UNCOMPRESS, ROCC_SET_LENGTH = 3, 0, 1, 2
 # every symbol include/snappy_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "sz_max_compressed_length", "sz_compress_blocks_hip", "sz_compress_stream_hip", "sz_pack_stream_hip",
-    "sz_uncompress_blocks_hip", "sz_compress", "sz_uncompress", "sz_get_uncompressed_length",
+    "sz_uncompress_blocks_hip", "sz_uncompress_packed_hip", "sz_compress", "sz_uncompress", "sz_get_uncompressed_length",
     "sz_rocc_cmd", "rocc_cmd", "sz_rocc_last_error", "sz_release_thread_resources", "sz_device_count",
     "sz_last_hip_error", "sz_strerror", "sz_version",
 )
@@ -72,6 +72,8 @@ def lib():
     L.sz_pack_stream_hip.restype = i32
     L.sz_uncompress_blocks_hip.argtypes = [vp, sz, vp, u32, vp, sz, vp, vp, vp]
     L.sz_uncompress_blocks_hip.restype = i32
+    L.sz_uncompress_packed_hip.argtypes = [vp, vp, u32, u64, vp, vp, vp, vp]
+    L.sz_uncompress_packed_hip.restype = i32
     L.sz_compress.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
     L.sz_compress.restype = i32
     L.sz_uncompress.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
@@ -171,6 +173,20 @@ def uncompress_blocks(src, src_stride, src_len, n_streams, dst_stride=BLOCK_SIZE
     _check(lib().sz_uncompress_blocks_hip(_ptr(src), src_stride, _ptr(src_len), n_streams, _ptr(dst), dst_stride,
                                           _ptr(out_len), _ptr(status), _stream_handle(stream)),
            "sz_uncompress_blocks_hip")
+    return dst, out_len, status
+
+
+def uncompress_packed(packed, offsets, n_blocks, total_ulen, dst=None, stream=None):
+    """Parallel decode of the fragments of one packed stream (pack_stream's layout and offsets);
+    returns (dst uint8[n_blocks*65536], out_len int32[n], status int32[n])."""
+    import torch
+    if dst is None:
+        dst = torch.empty(n_blocks * BLOCK_SIZE, dtype=torch.uint8, device=packed.device)
+    out_len = torch.empty(n_blocks, dtype=torch.int32, device=packed.device)
+    status = torch.empty(n_blocks, dtype=torch.int32, device=packed.device)
+    _check(lib().sz_uncompress_packed_hip(_ptr(packed), _ptr(offsets), n_blocks, total_ulen, _ptr(dst),
+                                          _ptr(out_len), _ptr(status), _stream_handle(stream)),
+           "sz_uncompress_packed_hip")
     return dst, out_len, status
 
 

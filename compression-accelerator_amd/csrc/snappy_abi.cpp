@@ -281,6 +281,21 @@ int sz_uncompress_blocks_hip(const void *d_src, size_t src_stride, const uint32_
     return SZ_OK;
 }
 
+int sz_uncompress_packed_hip(const void *d_packed, const uint64_t *d_off, uint32_t n_blocks,
+                             uint64_t total_ulen, void *d_dst, uint32_t *d_out_len, int32_t *d_status,
+                             void *stream)
+{
+    if (n_blocks == 0)
+        return total_ulen == 0 ? SZ_OK : SZ_EINVAL;
+    if (!d_packed || !d_off || !d_dst || !d_out_len || !d_status)
+        return SZ_EINVAL;
+    if (total_ulen == 0 || (total_ulen + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE != n_blocks)
+        return SZ_EINVAL;  // n_blocks must be ceil(total_ulen / 64 KiB)
+    SZ_HIP(szk::launch_uncompress_packed(d_packed, d_off, n_blocks, total_ulen, d_dst, d_out_len, d_status,
+                                         static_cast<hipStream_t>(stream)));
+    return SZ_OK;
+}
+
 /* --------------------------------------------------------------------- host-buffer API */
 
 int sz_get_uncompressed_length(const void *src, size_t n, size_t *result)

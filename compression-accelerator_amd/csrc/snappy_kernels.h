@@ -44,4 +44,10 @@ hipError_t launch_uncompress_streams(const void *d_src, uint64_t src_stride, con
                                      uint32_t n_streams, void *d_dst, uint64_t dst_stride,
                                      uint32_t *d_out_len, int32_t *d_status, hipStream_t stream);
 
+// The fragments of one packed stream (sz_pack_stream_hip layout), decoded in parallel: fragment b is
+// d_packed[d_off[b], d_off[b+1]) and lands at d_dst + b * 64 KiB.
+hipError_t launch_uncompress_packed(const void *d_packed, const uint64_t *d_off, uint32_t n_blocks,
+                                    uint64_t total_ulen, void *d_dst, uint32_t *d_out_len,
+                                    int32_t *d_status, hipStream_t stream);
+
 }  // namespace szk

@@ -1215,8 +1215,13 @@ __global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__rest
 // One wavefront per raw stream.  Elements are parsed serially (the format has no index); the
 // bytes of each element are moved by all 64 lanes.  Copies read back this wave's own earlier
 // stores to global memory: same wave, same address path, program order.
+// Two ways to name the streams: fixed stride + per-stream length, each a raw stream with its own
+// preamble (src_off == nullptr); or the fragments of ONE packed stream, fragment b = bytes
+// [src_off[b], src_off[b+1]) of src, a body without preamble that decodes to 64 KiB (the last one to
+// the rest of total_ulen) -- the layout sz_pack_stream_hip produces.
 __global__ __launch_bounds__(64) void uncompress_streams_kernel(
     const uint8_t *__restrict__ src, uint64_t src_stride, const uint32_t *__restrict__ src_len,
+    const uint64_t *__restrict__ src_off, uint64_t total_ulen,
     uint32_t n_streams, uint8_t *dst, uint64_t dst_stride, uint32_t *__restrict__ out_len,
     int32_t *__restrict__ status)
 {
@@ -1224,14 +1229,30 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
     const uint32_t b = blockIdx.x;
     if (b >= n_streams)
         return;
-    const uint8_t *__restrict__ in = src + (uint64_t)b * src_stride;
+    const uint8_t *__restrict__ in;
     uint8_t *out = dst + (uint64_t)b * dst_stride;
-    const uint32_t n = uni(src_len[b]);
+    uint32_t n;
     int32_t st = 0;
     uint32_t ip = 0, op = 0, ulen = 0;
+    if (src_off) {
+        const uint64_t o0 = src_off[b], o1 = src_off[b + 1];
+        in = src + o0;
+        const uint64_t len64 = o1 >= o0 ? o1 - o0 : ~0ull;
+        n = uni((uint32_t)(len64 < 0x7fffffffull ? len64 : 0x7fffffffull));
+        const uint64_t done = (uint64_t)b * kMaxBlock;
+        const uint64_t left = total_ulen > done ? total_ulen - done : 0;
+        ulen = uni((uint32_t)(left < kMaxBlock ? left : kMaxBlock));
+        if (len64 >= 0x7fffffffull || left == 0)
+            st = kStatusCorrupt;
+        else if ((uint64_t)ulen > dst_stride)
+            st = kStatusNoSpace;
+    } else {
+        in = src + (uint64_t)b * src_stride;
+        n = uni(src_len[b]);
+    }
 
     // preamble
-    {
+    if (!src_off) {
         uint32_t shiftv = 0;
         bool ok = false;
         for (uint32_t i = 0; i < 5 && i < n; i++) {
@@ -1516,8 +1537,22 @@ hipError_t launch_uncompress_streams(const void *d_src, uint64_t src_stride, con
     if (n_streams == 0)
         return hipSuccess;
     hipLaunchKernelGGL(uncompress_streams_kernel, dim3(n_streams), dim3(64), 0, stream,
-                       static_cast<const uint8_t *>(d_src), src_stride, d_src_len, n_streams,
+                       static_cast<const uint8_t *>(d_src), src_stride, d_src_len,
+                       static_cast<const uint64_t *>(nullptr), (uint64_t)0, n_streams,
                        static_cast<uint8_t *>(d_dst), dst_stride, d_out_len, d_status);
+    return hipGetLastError();
+}
+
+hipError_t launch_uncompress_packed(const void *d_packed, const uint64_t *d_off, uint32_t n_blocks,
+                                    uint64_t total_ulen, void *d_dst, uint32_t *d_out_len,
+                                    int32_t *d_status, hipStream_t stream)
+{
+    if (n_blocks == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(uncompress_streams_kernel, dim3(n_blocks), dim3(64), 0, stream,
+                       static_cast<const uint8_t *>(d_packed), (uint64_t)0,
+                       static_cast<const uint32_t *>(nullptr), d_off, total_ulen, n_blocks,
+                       static_cast<uint8_t *>(d_dst), (uint64_t)kMaxBlock, d_out_len, d_status);
     return hipGetLastError();
 }
 

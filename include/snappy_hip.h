@@ -102,6 +102,18 @@ int sz_uncompress_blocks_hip(const void *d_src, size_t src_stride, const uint32_
                              uint32_t n_streams, void *d_dst, size_t dst_stride,
                              uint32_t *d_out_len, int32_t *d_status, void *stream);
 
+/* The inverse of sz_pack_stream_hip for a caller that kept the offsets: fragment b of the packed
+ * stream is d_packed[d_off[b], d_off[b+1]) (a body, no preamble; d_off as written by
+ * sz_pack_stream_hip, d_off[0] = size of the stream's preamble) and decodes to
+ * d_dst + b*65536: 64 KiB each, the last one the rest of total_ulen.  n_blocks must be
+ * ceil(total_ulen / 65536).  All fragments are decoded in parallel (one wavefront each) -- the
+ * way to decompress one large snappy::Compress stream fast; without the offsets a stream has to
+ * be parsed serially (sz_uncompress_blocks_hip with one stream, sz_uncompress).
+ * d_out_len[b] / d_status[b] as for sz_uncompress_blocks_hip. */
+int sz_uncompress_packed_hip(const void *d_packed, const uint64_t *d_off, uint32_t n_blocks,
+                             uint64_t total_ulen, void *d_dst, uint32_t *d_out_len, int32_t *d_status,
+                             void *stream);
+
 /* ---- host-buffer convenience API (what the snappy:: facade and the RoCC surface call) ---- */
 
 /* Exactly the bytes of snappy::Compress(src, n): varint32(n) + bodies of consecutive 64 KiB

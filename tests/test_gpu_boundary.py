@@ -133,6 +133,58 @@ def test_device_pack_yields_the_whole_stream():
     assert o[0] == len(hdr) and (np.diff(o) == l[:nb]).all()
 
 
+def test_packed_stream_decodes_in_parallel_with_its_offsets():
+    """sz_uncompress_packed_hip: the inverse of the pack step.  (1) what this build packed, (2) a
+    stream that libsnappy 1.1.8 produced (golden), with fragment offsets recomputed by the oracle,
+    (3) wrong offsets or sizes are reported per fragment, not followed."""
+    import torch
+    P = pkg()
+    # (1) own stream, ragged last fragment
+    for data in (fuzzgen.corpus("mtg")[:65536 * 9 + 777], fuzzgen.gen("lz", 8, 65536 * 3).tobytes(),
+                 fuzzgen.corpus("random_ascii") + fuzzgen.corpus("random_ascii")[:31073]):
+        n = len(data)
+        src = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+        slots, lens, nb = P.compress_stream(src, n)
+        nh = 1 if n < 128 else (2 if n < 16384 else (3 if n < 2097152 else 4))
+        packed, offs = P.pack_stream(slots, P.SLOT_STRIDE, lens, nb, base=nh)
+        back, ol, st = P.uncompress_packed(packed, offs, nb, n)
+        torch.cuda.synchronize()
+        assert int(st.abs().sum().item()) == 0
+        assert back[:n].cpu().numpy().tobytes() == data
+        want_len = [min(65536, n - 65536 * b) for b in range(nb)]
+        assert ol.cpu().numpy().tolist() == want_len
+    # (2) the golden whole-file stream of all-mtg-cards.txt (libsnappy 1.1.8): 48 fragments
+    mtg = fuzzgen.corpus("mtg")
+    whole = oracle_lib.raw_compress(mtg)
+    with open(os.path.join(G, "golden_files.json")) as f:
+        gold = {e["name"]: e for e in json.load(f)["files"]}
+    assert sha(whole) == gold["all-mtg-cards.txt"]["out_sha256"]
+    nb = (len(mtg) + 65535) // 65536
+    body = [len(oracle_lib.raw_compress(mtg[b * 65536:(b + 1) * 65536])) - (3 if len(mtg[b * 65536:(b + 1) * 65536]) >= 16384 else 2)
+            for b in range(nb)]
+    nh = len(whole) - sum(body)
+    offs = np.concatenate([[nh], nh + np.cumsum(body)]).astype(np.uint64)
+    d_whole = torch.from_numpy(np.frombuffer(whole, dtype=np.uint8).copy()).cuda()
+    d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
+    back, ol, st = P.uncompress_packed(d_whole, d_offs, nb, len(mtg))
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0
+    assert back[:len(mtg)].cpu().numpy().tobytes() == mtg
+    # (3) damaged side information
+    bad = offs.copy()
+    bad[5] += 1  # fragments 4 and 5 now start / end in the middle of an element
+    back, ol, st = P.uncompress_packed(d_whole, torch.from_numpy(bad.view(np.int64)).cuda(), nb, len(mtg))
+    torch.cuda.synchronize()
+    stn = st.cpu().numpy()
+    assert stn[4] != 0 or stn[5] != 0
+    assert (np.delete(stn, [4, 5]) == 0).all()
+    back, ol, st = P.uncompress_packed(d_whole, d_offs, nb, len(mtg) - 5)
+    torch.cuda.synchronize()
+    assert st.cpu().numpy()[-1] != 0  # the last fragment holds 5 bytes more than announced
+    with pytest.raises(P.SnappyHipError):
+        P.uncompress_packed(d_whole, d_offs, nb + 1, len(mtg))  # n_blocks must match total_ulen
+
+
 def test_batch_decompress_round_trip_all_kinds():
     import torch
     P = pkg()
