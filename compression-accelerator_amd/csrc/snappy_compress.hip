@@ -1,4 +1,4 @@
-// snappy_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the Snappy block compressor.
+// snappy_compress.hip -- hand-written gfx950 (CDNA4) kernels of the Snappy block compressor.
 //
 // Hot path: hash table (a2) + match finder (a3) + pointer advance (a4) +
 // match extension (a5) + copy element encoder (a6) + literal emission (a7) + preamble (a8) +
@@ -20,11 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "snappy_kernels.h"
+#include "wave_utils.h"
 
 namespace szk {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic build only (tools/chainprof.hip compiles this file with -DSZ_PROF): cycle stamps per
 // phase, summed per block into g_prof.  Expands to nothing in the product build.
@@ -46,7 +44,6 @@ __device__ unsigned long long g_prof[64];  // [0,32): waves with the table in LD
 #endif
 
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
-static constexpr uint32_t kMaxBlock = 65536u;
 static constexpr uint32_t kMaxTable = 16384u;
 static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
 
@@ -74,51 +71,6 @@ static constexpr ProbeSchedule make_probe_schedule()
     return s;
 }
 __device__ const ProbeSchedule g_probe = make_probe_schedule();
-
-// ------------------------------------------------------------------------------- helpers
-
-typedef u32x4 u32x4_u __attribute__((aligned(1)));
-
-__device__ __forceinline__ uint32_t ld32(const uint8_t *p)
-{
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);  // gfx950: one (possibly unaligned) global_load_dword
-    return v;
-}
-__device__ __forceinline__ uint64_t ld64(const uint8_t *p)
-{
-    uint64_t v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
-}
-__device__ __forceinline__ u32x4 ld128(const uint8_t *p)
-{
-    u32x4 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
-}
-__device__ __forceinline__ u32x4 ld128_nt(const uint8_t *p)
-{
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
-}
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l)
-{
-    return __builtin_amdgcn_readlane(v, uni(l));
-}
-__device__ __forceinline__ uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
-
-// dword at byte offset `off` of a block of n bytes; bytes past the end read as 0 (never touched)
-__device__ __forceinline__ uint32_t ld32_clamped(const uint8_t *in, uint32_t off, uint32_t n)
-{
-    if (off + 4 <= n)
-        return ld32(in + off);
-    uint32_t v = 0;
-    if (off < n) v |= in[off];
-    if (off + 1 < n) v |= (uint32_t)in[off + 1] << 8;
-    if (off + 2 < n) v |= (uint32_t)in[off + 2] << 16;
-    return v;
-}
 
 // Number of leading equal bytes (4..16) of two 16-byte strings whose first 4 bytes are equal.
 __device__ __forceinline__ uint32_t matchlen16(uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b1,
@@ -152,53 +104,6 @@ __device__ __forceinline__ uint32_t matchlen32(const u32x4 &a, const u32x4 &a2, 
     m = umin3(m, diff_bit(a2.x, b2.x, 128), diff_bit(a2.y, b2.y, 160));
     m = umin3(m, diff_bit(a2.z, b2.z, 192), diff_bit(a2.w, b2.w, 224));
     return (m < 256u ? m : 256u) >> 3;
-}
-
-// Cooperative byte copy by one wave, dst-aligned 16-byte stores in the bulk; long copies stream
-// with non-temporal loads/stores, kDepth KiB in flight (0: none; the depth costs 4 VGPRs per KiB).
-template <int kDepth = 16>
-__device__ __forceinline__ void wave_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s,
-                                          uint32_t len, uint32_t lane)
-{
-    if (len <= 64) {
-        if (lane < len)
-            d[lane] = s[lane];
-        return;
-    }
-    uint32_t head = (16u - (uint32_t)((uintptr_t)d & 15u)) & 15u;
-    if (lane < head)
-        d[lane] = s[lane];
-    d += head;
-    s += head;
-    len -= head;
-    const uint32_t nvec = len >> 4;
-    uint32_t i = lane;
-    if (kDepth > 0 && nvec >= 64u * kDepth) {
-        for (; i + 64u * (kDepth - 1) < nvec; i += 64u * kDepth) {
-            u32x4 q[kDepth > 0 ? kDepth : 1];
-#pragma unroll
-            for (int u = 0; u < kDepth; u++)
-                q[u] = ld128_nt(s + 16 * (size_t)(i + 64 * u));
-#pragma unroll
-            for (int u = 0; u < kDepth; u++)
-                __builtin_nontemporal_store(q[u], reinterpret_cast<u32x4 *>(d + 16 * (size_t)(i + 64 * u)));
-        }
-    }
-    for (; i + 192 < nvec; i += 256) {
-        u32x4 q0 = ld128(s + 16 * (size_t)i);
-        u32x4 q1 = ld128(s + 16 * (size_t)(i + 64));
-        u32x4 q2 = ld128(s + 16 * (size_t)(i + 128));
-        u32x4 q3 = ld128(s + 16 * (size_t)(i + 192));
-        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)i) = q0;
-        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)(i + 64)) = q1;
-        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)(i + 128)) = q2;
-        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)(i + 192)) = q3;
-    }
-    for (; i < nvec; i += 64)
-        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)i) = ld128(s + 16 * (size_t)i);
-    const uint32_t done = nvec << 4;
-    if (lane < (len & 15u))
-        d[done + lane] = s[done + lane];
 }
 
 // Literal element (a7): tag (len-1)<<2 for len<=60 (CompressionAccelerator.scala:172,231-233);
@@ -315,27 +220,6 @@ __device__ __forceinline__ uint32_t sel6(uint32_t r0, uint32_t r1, uint32_t r2, 
     v = (b == 4) ? r4 : v;
     v = (b == 5) ? r5 : v;
     return v;
-}
-
-// Inclusive prefix sum over the 64 lanes with DPP (no LDS): Hillis-Steele inside each row of 16,
-// then row_bcast:15 / row_bcast:31 to carry the row totals.
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
-{
-#define SZ_DPP(v, ctrl, rmask) (uint32_t) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, true)
-    x += SZ_DPP(x, 0x111, 0xf);  // row_shr:1
-    x += SZ_DPP(x, 0x112, 0xf);  // row_shr:2
-    x += SZ_DPP(x, 0x114, 0xf);  // row_shr:4
-    x += SZ_DPP(x, 0x118, 0xf);  // row_shr:8
-    x += SZ_DPP(x, 0x142, 0xa);  // row_bcast:15 -> rows 1,3
-    x += SZ_DPP(x, 0x143, 0xc);  // row_bcast:31 -> rows 2,3
-#undef SZ_DPP
-    return x;
-}
-
-__device__ __forceinline__ uint64_t below63(uint32_t k) { return (1ull << k) - 1; }  // bits 0..k-1, k <= 63
-__device__ __forceinline__ uint64_t lanes_below(uint32_t k)  // bits 0..k-1, k in 0..64
-{
-    return k >= 64 ? ~0ull : ((1ull << k) - 1);
 }
 
 // ------------------------------------------------------------------------ compress kernel
@@ -1137,332 +1021,6 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
         scratch_gen[my_slot] = gen;
 }
 
-// ---------------------------------------------------------------------- stream packing (8f-2)
-
-// Exclusive prefix sum of n lengths (+base) by one 1024-thread workgroup.
-__global__ __launch_bounds__(1024) void scan_lengths_kernel(const uint32_t *__restrict__ len, uint32_t n,
-                                                            uint64_t base, uint64_t max_len,
-                                                            uint64_t *__restrict__ off)
-{
-    __shared__ uint64_t part[1024];
-    __shared__ uint32_t bad;
-    const uint32_t t = threadIdx.x;
-    if (t == 0)
-        bad = 0;
-    __syncthreads();
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t lo = t * per < n ? t * per : n;
-    const uint32_t hi = lo + per < n ? lo + per : n;
-    // a length above the slot size is one of the compress kernels' error markers (0xffffffff: block
-    // longer than 64 KiB, 0xfffffffe: internal): it counts as 0 and the total becomes UINT64_MAX
-    uint64_t s = 0;
-    bool any_bad = false;
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t v = len[i];
-        any_bad |= v > max_len;
-        s += v > max_len ? 0u : v;
-    }
-    if (any_bad)
-        atomicOr(&bad, 1u);
-    part[t] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
-        uint64_t add = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += add;
-        __syncthreads();
-    }
-    uint64_t run = base + (t ? part[t - 1] : 0);
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t v = len[i];
-        off[i] = run;
-        run += v > max_len ? 0u : v;
-    }
-    if (t == 1023)
-        off[n] = bad ? ~0ull : base + part[1023];
-}
-
-__global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__restrict__ slots,
-                                                           uint64_t slot_stride,
-                                                           const uint32_t *__restrict__ len,
-                                                           const uint64_t *__restrict__ off,
-                                                           uint8_t *__restrict__ packed)
-{
-    const uint32_t b = blockIdx.x, t = threadIdx.x;
-    const uint8_t *s = slots + (uint64_t)b * slot_stride;
-    uint8_t *d = packed + off[b];
-    uint32_t n = len[b];
-    if (n > slot_stride)  // error marker: nothing to move (the scan reports it)
-        return;
-    uint32_t head = (16u - (uint32_t)((uintptr_t)d & 15u)) & 15u;
-    if (head > n)
-        head = n;
-    if (t < head)
-        d[t] = s[t];
-    d += head;
-    s += head;
-    n -= head;
-    const uint32_t nvec = n >> 4;
-    for (uint32_t i = t; i < nvec; i += 256)
-        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)i) = ld128(s + 16 * (size_t)i);
-    const uint32_t done = nvec << 4;
-    if (t < (n & 15u))
-        d[done + t] = s[done + t];
-}
-
-// -------------------------------------------------------------------- decompression (8f-1)
-
-// One wavefront per raw stream.  Elements are parsed serially (the format has no index); the
-// bytes of each element are moved by all 64 lanes.  Copies read back this wave's own earlier
-// stores to global memory: same wave, same address path, program order.
-// Two ways to name the streams: fixed stride + per-stream length, each a raw stream with its own
-// preamble (src_off == nullptr); or the fragments of ONE packed stream, fragment b = bytes
-// [src_off[b], src_off[b+1]) of src, a body without preamble that decodes to 64 KiB (the last one to
-// the rest of total_ulen) -- the layout sz_pack_stream_hip produces.
-__global__ __launch_bounds__(64) void uncompress_streams_kernel(
-    const uint8_t *__restrict__ src, uint64_t src_stride, const uint32_t *__restrict__ src_len,
-    const uint64_t *__restrict__ src_off, uint64_t total_ulen,
-    uint32_t n_streams, uint8_t *dst, uint64_t dst_stride, uint32_t *__restrict__ out_len,
-    int32_t *__restrict__ status)
-{
-    const uint32_t lane = threadIdx.x;
-    const uint32_t b = blockIdx.x;
-    if (b >= n_streams)
-        return;
-    const uint8_t *__restrict__ in;
-    uint8_t *out = dst + (uint64_t)b * dst_stride;
-    uint32_t n;
-    int32_t st = 0;
-    uint32_t ip = 0, op = 0, ulen = 0;
-    if (src_off) {
-        const uint64_t o0 = src_off[b], o1 = src_off[b + 1];
-        in = src + o0;
-        const uint64_t len64 = o1 >= o0 ? o1 - o0 : ~0ull;
-        n = uni((uint32_t)(len64 < 0x7fffffffull ? len64 : 0x7fffffffull));
-        const uint64_t done = (uint64_t)b * kMaxBlock;
-        const uint64_t left = total_ulen > done ? total_ulen - done : 0;
-        ulen = uni((uint32_t)(left < kMaxBlock ? left : kMaxBlock));
-        if (len64 >= 0x7fffffffull || left == 0)
-            st = kStatusCorrupt;
-        else if ((uint64_t)ulen > dst_stride)
-            st = kStatusNoSpace;
-    } else {
-        in = src + (uint64_t)b * src_stride;
-        n = uni(src_len[b]);
-    }
-
-    // preamble
-    if (!src_off) {
-        uint32_t shiftv = 0;
-        bool ok = false;
-        for (uint32_t i = 0; i < 5 && i < n; i++) {
-            const uint32_t c = uni(in[i]);
-            if (i == 4 && c > 0x0f)
-                break;
-            ulen |= (c & 0x7f) << shiftv;
-            shiftv += 7;
-            if (c < 0x80) {
-                ok = true;
-                ip = i + 1;
-                break;
-            }
-        }
-        if (!ok)
-            st = kStatusCorrupt;
-        else if ((uint64_t)ulen > dst_stride)
-            st = kStatusNoSpace;
-    }
-
-    // ---- windowed decode: the tags of 64 candidate element starts are decoded at once (lane l looks
-    // at compressed byte ip + l), then the elements that really start in the window are walked with
-    // v_readlane -- no dependent tag load per element.  Needs ip + 72 <= n; the tail below is serial.
-    while (st == 0 && (uint64_t)ip + 72 <= n && n <= 0x7fffffffu) {  // (32-bit offset sums below)
-        const uint64_t x = ld64(in + ip + lane);
-        const uint32_t tag = (uint32_t)x & 0xffu;
-        const uint32_t extra = (uint32_t)(x >> 8);
-        const uint32_t kind_v = tag & 3u;
-        const uint32_t l6 = tag >> 2;
-        // compressed size, produced bytes, (literal: header bytes | copy: offset) -- selects, no branches
-        const bool is_lit_v = kind_v == 0;
-        const uint32_t nb = (is_lit_v && l6 >= 60) ? l6 - 59u : 0u;                  // literal: length bytes
-        const uint32_t lenm1 = nb == 0 ? l6 : (extra & (0xffffffffu >> (32u - 8u * nb)));
-        const uint32_t c_off = kind_v == 1 ? (((tag >> 5) << 8) | (extra & 0xffu))
-                                           : (kind_v == 2 ? (extra & 0xffffu) : extra);
-        const uint32_t aux_v = is_lit_v ? 1u + nb : c_off;
-        const uint32_t olen_v = is_lit_v ? lenm1 + 1u                                  // wraps to 0 for 2^32: rejected below
-                                         : (kind_v == 1 ? (l6 & 7u) + 4u : l6 + 1u);
-        const uint32_t size_v = is_lit_v ? aux_v + olen_v                              // may wrap: the bound checks use 64 bits
-                                         : (kind_v == 1 ? 2u : (kind_v == 2 ? 3u : 5u));
-        // ---- which lanes start an element?  Every lane knows where an element starting at it would
-        // end (63 = outside the window, also for a literal that cannot be valid: lane 63 never starts
-        // an element of this window, so it can stand for "out" and absorb the walk); the serial part
-        // is one v_readlane per element.
-        const bool bad_v = kind_v == 0 && (olen_v == 0 || (uint64_t)ip + lane + aux_v + olen_v > n);
-        const uint64_t end_v = (uint64_t)lane + (kind_v == 0 ? (uint64_t)aux_v + olen_v : (uint64_t)size_v);
-        const uint32_t nx_v = (bad_v || end_v > 62 || lane == 63) ? 63u : (uint32_t)end_v;
-        uint64_t Pm = 0;
-        uint32_t j = 0;
-        do {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                Pm |= 1ull << j;
-                j = lane_get(nx_v, j);
-            }
-        } while (j != 63);
-        Pm &= ~(1ull << 63);
-        if (__ballot(bad_v) & Pm) {
-            st = kStatusCorrupt;
-            break;
-        }
-        {   // the last element may reach past the window: the next window starts where it really ends
-            const uint32_t e_last = 63u - (uint32_t)__builtin_clzll(Pm);
-            j = e_last + lane_get(size_v, e_last);  // (sizes of valid elements fit: n < 2^31)
-        }
-        // ---- output offsets of the window's elements
-        const bool is_elem = (Pm >> lane) & 1;
-        const uint32_t olen = is_elem ? olen_v : 0u;
-        const uint32_t incl = wave_inclusive_sum(olen);
-        const uint32_t o_rel = incl - olen;  // offset inside this window's output
-        const uint32_t total = lane_get(incl, 63);
-        if ((uint64_t)op + total > ulen) {
-            st = kStatusCorrupt;
-            break;
-        }
-        const bool is_copy = is_elem && kind_v != 0;
-        if (__ballot(is_copy && (aux_v == 0 || aux_v > op + o_rel)) != 0) {
-            st = kStatusCorrupt;
-            break;
-        }
-        // A copy whose source ends before this window's output begins ("far") depends on nothing that
-        // is produced here, nor does a literal: those are all done at once, one element per lane,
-        // four bytes per step.  Copies that read this window's own output ("near") follow in order.
-        const bool far_copy = is_copy && aux_v >= o_rel + olen;
-        const bool near_copy = is_copy && !far_copy;
-        const bool small_lit = is_elem && kind_v == 0 && olen <= 64;
-        const bool big_lit = is_elem && kind_v == 0 && olen > 64;
-        {
-            const bool par = far_copy || small_lit;
-            const uint8_t *sp = small_lit ? in + ip + lane + aux_v : out + op + o_rel - aux_v;
-            uint8_t *dp = out + op + o_rel;
-            const uint32_t mylen = par ? olen : 0u;
-            // 16 bytes per step while any element has that many left, then 8, 4 and up to 3 single
-            // bytes: few predicated memory instructions for the short elements that dominate.
-            // (sources and destinations of different lanes never overlap: far copies end before the
-            // window's output begins, literals come from the input)
-            uint32_t i = 0;
-            while (__ballot(i + 16 <= mylen) != 0) {
-                if (i + 16 <= mylen) {
-                    const u32x4 v = ld128(sp + i);
-                    __builtin_memcpy(dp + i, &v, 16);
-                    i += 16;
-                }
-            }
-            // the 8/4/2/1-byte pieces: all loads, then all stores (one memory latency, not four)
-            const uint32_t i8 = i, i4 = i8 + (mylen & 8u), i2 = i4 + (mylen & 4u), i1 = i2 + (mylen & 2u);
-            uint64_t v8 = 0;
-            uint32_t v4 = 0;
-            uint16_t v2 = 0;
-            uint8_t v1 = 0;
-            if (mylen & 8u) v8 = ld64(sp + i8);
-            if (mylen & 4u) v4 = ld32(sp + i4);
-            if (mylen & 2u) __builtin_memcpy(&v2, sp + i2, 2);
-            if (mylen & 1u) v1 = sp[i1];
-            if (mylen & 8u) __builtin_memcpy(dp + i8, &v8, 8);
-            if (mylen & 4u) __builtin_memcpy(dp + i4, &v4, 4);
-            if (mylen & 2u) __builtin_memcpy(dp + i2, &v2, 2);
-            if (mylen & 1u) dp[i1] = v1;
-        }
-        // literals longer than 64 bytes: cooperative copies (their data comes from the input)
-        for (uint64_t B = __ballot(big_lit); B; B &= B - 1) {
-            const uint32_t e = ctz64(B);
-            wave_copy<6>(out + op + lane_get(o_rel, e), in + ip + e + lane_get(aux_v, e), lane_get(olen_v, e), lane);
-        }
-        // near copies, in stream order (they may read what the steps above and each other wrote)
-        for (uint64_t N = __ballot(near_copy); N; N &= N - 1) {
-            const uint32_t e = ctz64(N);
-            const uint32_t len = lane_get(olen_v, e), off = lane_get(aux_v, e), o = op + lane_get(o_rel, e);
-            // (off >= len: plain copy; else the last `off` bytes repeat -- the division only then)
-            const uint32_t k = off >= len ? lane : lane % off;
-            if (lane < len)
-                out[o + lane] = out[o - off + k];
-        }
-        op += total;
-        if (st != 0)
-            break;
-        ip += j;
-    }
-
-    while (st == 0 && ip < n) {
-        // tag + up to 4 trailing bytes in one go when they are in bounds
-        uint32_t tag, extra = 0;
-        if (ip + 5 <= n) {
-            const uint64_t x = ld64(in + ip) ;
-            tag = uni((uint32_t)x & 0xff);
-            extra = uni((uint32_t)(x >> 8));
-        } else {
-            tag = uni(in[ip]);
-            for (uint32_t k = 1; k < 5 && ip + k < n; k++)
-                extra |= uni((uint32_t)in[ip + k]) << (8 * (k - 1));
-        }
-        const uint32_t kind = tag & 3;
-        if (kind == 0) {
-            uint32_t len = (tag >> 2) + 1, hdr = 1;
-            if (len > 60) {
-                const uint32_t nb = len - 60;
-                if (ip + 1 + nb > n) {
-                    st = kStatusCorrupt;
-                    break;
-                }
-                len = (nb == 4 ? extra : (extra & ((1u << (8 * nb)) - 1))) + 1;
-                hdr = 1 + nb;
-                if (len == 0) {  // 2^32 wrap
-                    st = kStatusCorrupt;
-                    break;
-                }
-            }
-            if ((uint64_t)ip + hdr + len > n || (uint64_t)op + len > ulen) {
-                st = kStatusCorrupt;
-                break;
-            }
-            wave_copy<6>(out + op, in + ip + hdr, len, lane);
-            ip += hdr + len;
-            op += len;
-        } else {
-            uint32_t len, off, hdr;
-            if (kind == 1) {
-                hdr = 2;
-                len = ((tag >> 2) & 7) + 4;
-                off = ((tag >> 5) << 8) | (extra & 0xff);
-            } else if (kind == 2) {
-                hdr = 3;
-                len = (tag >> 2) + 1;
-                off = extra & 0xffff;
-            } else {
-                hdr = 5;
-                len = (tag >> 2) + 1;
-                off = extra;
-            }
-            if (ip + hdr > n || off == 0 || off > op || (uint64_t)op + len > ulen) {
-                st = kStatusCorrupt;
-                break;
-            }
-            // len <= 64: one byte per lane; an overlapping copy (off < len) repeats the last off
-            // bytes, so lane i reads byte (i mod off) of the window [op-off, op).
-            const uint32_t k = off >= len ? lane : lane % off;
-            if (lane < len)
-                out[op + lane] = out[op - off + k];
-            ip += hdr;
-            op += len;
-        }
-    }
-    if (st == 0 && op != ulen)
-        st = kStatusCorrupt;
-    if (lane == 0) {
-        out_len[b] = st == 0 ? op : 0;
-        status[b] = st;
-    }
-}
-
 // ------------------------------------------------------------------------------ launchers
 
 static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len, uint64_t total_len,
@@ -1514,46 +1072,6 @@ hipError_t launch_compress_stream(const void *d_src, uint64_t n, void *d_slots, 
         return hipSuccess;
     const uint32_t n_blocks = (uint32_t)((n + kMaxBlock - 1) / kMaxBlock);
     return launch_any(d_src, kMaxBlock, nullptr, n, n_blocks, d_slots, slot_stride, d_len, flags, dual, stream);
-}
-
-hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const uint32_t *d_len,
-                              uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
-                              hipStream_t stream)
-{
-    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, stream, d_len, n_blocks, base, slot_stride, d_off);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || n_blocks == 0)
-        return e;
-    hipLaunchKernelGGL(gather_slots_kernel, dim3(n_blocks), dim3(256), 0, stream,
-                       static_cast<const uint8_t *>(d_slots), slot_stride, d_len, d_off,
-                       static_cast<uint8_t *>(d_packed));
-    return hipGetLastError();
-}
-
-hipError_t launch_uncompress_streams(const void *d_src, uint64_t src_stride, const uint32_t *d_src_len,
-                                     uint32_t n_streams, void *d_dst, uint64_t dst_stride,
-                                     uint32_t *d_out_len, int32_t *d_status, hipStream_t stream)
-{
-    if (n_streams == 0)
-        return hipSuccess;
-    hipLaunchKernelGGL(uncompress_streams_kernel, dim3(n_streams), dim3(64), 0, stream,
-                       static_cast<const uint8_t *>(d_src), src_stride, d_src_len,
-                       static_cast<const uint64_t *>(nullptr), (uint64_t)0, n_streams,
-                       static_cast<uint8_t *>(d_dst), dst_stride, d_out_len, d_status);
-    return hipGetLastError();
-}
-
-hipError_t launch_uncompress_packed(const void *d_packed, const uint64_t *d_off, uint32_t n_blocks,
-                                    uint64_t total_ulen, void *d_dst, uint32_t *d_out_len,
-                                    int32_t *d_status, hipStream_t stream)
-{
-    if (n_blocks == 0)
-        return hipSuccess;
-    hipLaunchKernelGGL(uncompress_streams_kernel, dim3(n_blocks), dim3(64), 0, stream,
-                       static_cast<const uint8_t *>(d_packed), (uint64_t)0,
-                       static_cast<const uint32_t *>(nullptr), d_off, total_ulen, n_blocks,
-                       static_cast<uint8_t *>(d_dst), (uint64_t)kMaxBlock, d_out_len, d_status);
-    return hipGetLastError();
 }
 
 }  // namespace szk

@@ -1,5 +1,5 @@
 // snappy_kernels.h -- internal launch interface between the C ABI (snappy_abi.cpp) and the
-// gfx950 kernels (snappy_kernels.hip).  Not installed; the public boundary is include/snappy_hip.h.
+// gfx950 kernels (snappy_compress.hip, snappy_pack.hip, snappy_uncompress.hip; shared device helpers: wave_utils.h).  Not installed; the public boundary is include/snappy_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

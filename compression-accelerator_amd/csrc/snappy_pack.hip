@@ -1,0 +1,94 @@
+// snappy_pack.hip -- turns the per-block slots of the compressor into the single stream that
+// snappy::Compress emits: exclusive scan of the lengths + gather.
+#include "wave_utils.h"
+
+namespace szk {
+
+// ---------------------------------------------------------------------- stream packing (8f-2)
+
+// Exclusive prefix sum of n lengths (+base) by one 1024-thread workgroup.
+__global__ __launch_bounds__(1024) void scan_lengths_kernel(const uint32_t *__restrict__ len, uint32_t n,
+                                                            uint64_t base, uint64_t max_len,
+                                                            uint64_t *__restrict__ off)
+{
+    __shared__ uint64_t part[1024];
+    __shared__ uint32_t bad;
+    const uint32_t t = threadIdx.x;
+    if (t == 0)
+        bad = 0;
+    __syncthreads();
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = t * per < n ? t * per : n;
+    const uint32_t hi = lo + per < n ? lo + per : n;
+    // a length above the slot size is one of the compress kernels' error markers (0xffffffff: block
+    // longer than 64 KiB, 0xfffffffe: internal): it counts as 0 and the total becomes UINT64_MAX
+    uint64_t s = 0;
+    bool any_bad = false;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = len[i];
+        any_bad |= v > max_len;
+        s += v > max_len ? 0u : v;
+    }
+    if (any_bad)
+        atomicOr(&bad, 1u);
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+        uint64_t add = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    uint64_t run = base + (t ? part[t - 1] : 0);
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = len[i];
+        off[i] = run;
+        run += v > max_len ? 0u : v;
+    }
+    if (t == 1023)
+        off[n] = bad ? ~0ull : base + part[1023];
+}
+
+__global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__restrict__ slots,
+                                                           uint64_t slot_stride,
+                                                           const uint32_t *__restrict__ len,
+                                                           const uint64_t *__restrict__ off,
+                                                           uint8_t *__restrict__ packed)
+{
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    const uint8_t *s = slots + (uint64_t)b * slot_stride;
+    uint8_t *d = packed + off[b];
+    uint32_t n = len[b];
+    if (n > slot_stride)  // error marker: nothing to move (the scan reports it)
+        return;
+    uint32_t head = (16u - (uint32_t)((uintptr_t)d & 15u)) & 15u;
+    if (head > n)
+        head = n;
+    if (t < head)
+        d[t] = s[t];
+    d += head;
+    s += head;
+    n -= head;
+    const uint32_t nvec = n >> 4;
+    for (uint32_t i = t; i < nvec; i += 256)
+        *reinterpret_cast<u32x4 *>(d + 16 * (size_t)i) = ld128(s + 16 * (size_t)i);
+    const uint32_t done = nvec << 4;
+    if (t < (n & 15u))
+        d[done + t] = s[done + t];
+}
+
+hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const uint32_t *d_len,
+                              uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
+                              hipStream_t stream)
+{
+    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, stream, d_len, n_blocks, base, slot_stride, d_off);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || n_blocks == 0)
+        return e;
+    hipLaunchKernelGGL(gather_slots_kernel, dim3(n_blocks), dim3(256), 0, stream,
+                       static_cast<const uint8_t *>(d_slots), slot_stride, d_len, d_off,
+                       static_cast<uint8_t *>(d_packed));
+    return hipGetLastError();
+}
+
+}  // namespace szk

@@ -1,7 +1,7 @@
 // tools/chainprof.hip -- diagnostic build of the compressor with per-phase cycle stamps.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSZ_PROF -I../include -I../compression-accelerator_amd/csrc chainprof.hip -o chainprof
 // usage: chainprof <raw input file> [n_blocks]   (blocks = consecutive 64 KiB windows, tiled)
-#include "../compression-accelerator_amd/csrc/snappy_kernels.hip"
+#include "../compression-accelerator_amd/csrc/snappy_compress.hip"
 #include <stdio.h>
 #include <vector>
 int main(int argc, char** argv){

@@ -2,7 +2,7 @@
 // separately for the waves whose table is in LDS and those whose table is in global memory.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSZ_PROF -I../include -I../compression-accelerator_amd/csrc chainprof2.hip -o chainprof2
 // usage: chainprof2 <raw input file> [n_blocks]
-#include "../compression-accelerator_amd/csrc/snappy_kernels.hip"
+#include "../compression-accelerator_amd/csrc/snappy_compress.hip"
 #include <stdio.h>
 #include <vector>
 int main(int argc, char **argv)
