@@ -139,8 +139,8 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             const uint8_t *sp = small_lit ? in + ip + lane + aux_v : out + op + o_rel - aux_v;
             uint8_t *dp = out + op + o_rel;
             const uint32_t mylen = par ? olen : 0u;
-            // 16 bytes per step while any element has that many left, then 8, 4 and up to 3 single
-            // bytes: few predicated memory instructions for the short elements that dominate.
+            // 16 bytes per step while any element has that many left, then the rest in one step: few
+            // predicated memory instructions for the short elements that dominate.
             // (sources and destinations of different lanes never overlap: far copies end before the
             // window's output begins, literals come from the input)
             uint32_t i = 0;
@@ -151,20 +151,19 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
                     i += 16;
                 }
             }
-            // the 8/4/2/1-byte pieces: all loads, then all stores (one memory latency, not four)
-            const uint32_t i8 = i, i4 = i8 + (mylen & 8u), i2 = i4 + (mylen & 4u), i1 = i2 + (mylen & 2u);
-            uint64_t v8 = 0;
-            uint32_t v4 = 0;
-            uint16_t v2 = 0;
-            uint8_t v1 = 0;
-            if (mylen & 8u) v8 = ld64(sp + i8);
-            if (mylen & 4u) v4 = ld32(sp + i4);
-            if (mylen & 2u) __builtin_memcpy(&v2, sp + i2, 2);
-            if (mylen & 1u) v1 = sp[i1];
-            if (mylen & 8u) __builtin_memcpy(dp + i8, &v8, 8);
-            if (mylen & 4u) __builtin_memcpy(dp + i4, &v4, 4);
-            if (mylen & 2u) __builtin_memcpy(dp + i2, &v2, 2);
-            if (mylen & 1u) dp[i1] = v1;
+            // the remaining r = 0..15 bytes, memcpy style: both ends of the rest with one size (the two
+            // pieces overlap in the middle), so every lane is in exactly one of three classes
+            const uint32_t r = mylen - i;
+            const bool c8 = r >= 8, c4 = r >= 4 && r < 8, c1 = r >= 1 && r < 4;
+            uint64_t a8 = 0, b8 = 0;
+            uint32_t a4 = 0, b4 = 0;
+            uint8_t a1 = 0, m1 = 0, b1 = 0;
+            if (c8) { a8 = ld64(sp + i); b8 = ld64(sp + mylen - 8); }
+            if (c4) { a4 = ld32(sp + i); b4 = ld32(sp + mylen - 4); }
+            if (c1) { a1 = sp[i]; m1 = sp[i + (r >> 1)]; b1 = sp[mylen - 1]; }
+            if (c8) { __builtin_memcpy(dp + i, &a8, 8); __builtin_memcpy(dp + mylen - 8, &b8, 8); }
+            if (c4) { __builtin_memcpy(dp + i, &a4, 4); __builtin_memcpy(dp + mylen - 4, &b4, 4); }
+            if (c1) { dp[i] = a1; dp[i + (r >> 1)] = m1; dp[mylen - 1] = b1; }
         }
         // literals longer than 64 bytes: cooperative copies (their data comes from the input)
         for (uint64_t B = __ballot(big_lit); B; B &= B - 1) {
