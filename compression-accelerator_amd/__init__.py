@@ -30,7 +30,8 @@ ROCC_CHANNEL, ROCC_COMPRESS, ROCC_UNCOMPRESS, ROCC_SET_LENGTH = 3, 0, 1, 2
 ABI_SYMBOLS = (
     "sz_max_compressed_length", "sz_compress_blocks_hip", "sz_compress_stream_hip", "sz_pack_stream_hip",
     "sz_uncompress_blocks_hip", "sz_uncompress_packed_hip", "sz_compress", "sz_uncompress", "sz_get_uncompressed_length",
-    "sz_rocc_cmd", "rocc_cmd", "sz_rocc_last_error", "sz_release_thread_resources", "sz_device_count",
+    "sz_rocc_cmd", "rocc_cmd", "sz_rocc_last_error", "sz_release_thread_resources",
+    "sz_release_stream_resources", "sz_device_count",
     "sz_last_hip_error", "sz_strerror", "sz_version",
 )
 
@@ -86,6 +87,8 @@ def lib():
     L.rocc_cmd.restype = u64
     L.sz_rocc_last_error.restype = i32
     L.sz_release_thread_resources.restype = None
+    L.sz_release_stream_resources.argtypes = [vp]
+    L.sz_release_stream_resources.restype = i32
     L.sz_device_count.restype = i32
     L.sz_last_hip_error.restype = i32
     L.sz_strerror.argtypes = [i32]

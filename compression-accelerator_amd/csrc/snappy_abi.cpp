@@ -216,6 +216,17 @@ const char *sz_strerror(int code)
 
 void sz_release_thread_resources(void) { tl_ws.release(); }
 
+int sz_release_stream_resources(void *stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return SZ_ENODEV;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SZ_HIP(hipStreamSynchronize(s));  // the workspace may still be in use by launches on this stream
+    drop_dual_scratch(dev, s);
+    return SZ_OK;
+}
+
 /* ------------------------------------------------------------------ device-resident API */
 
 int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *d_in_len,

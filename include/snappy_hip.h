@@ -141,6 +141,10 @@ int sz_rocc_last_error(void);
 /* ---- misc ------------------------------------------------------------------------------- */
 /* Frees the calling thread's cached device workspace (used by the host-buffer API). */
 void sz_release_thread_resources(void);
+/* Frees the 128 MiB workspace the compress entry points keep for `stream` on the current device
+ * (waits for the stream first).  Call it before destroying a stream that was used for compression
+ * if the process creates many; the next compress call on the stream allocates a new one. */
+int sz_release_stream_resources(void *stream);
 int sz_device_count(void);            /* number of visible GPUs (0 if none / no driver) */
 int sz_last_hip_error(void);          /* last hipError_t seen by this thread */
 const char *sz_strerror(int code);

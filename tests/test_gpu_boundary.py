@@ -545,3 +545,29 @@ def test_pack_reports_error_markers_instead_of_following_them():
     assert o[0] == 3 and o[1] == 3 + ln[0] and o[2] == o[1] + ln[1] and o[3] == o[2] and o[4] == o[3] + ln[3]
     body0 = packed[3:3 + int(ln[0])].cpu().numpy().tobytes()
     assert body0 == oracle_lib.raw_compress(blocks[0])[3:]
+
+
+def test_release_stream_resources_and_reuse():
+    """The per-stream multi-wave workspace can be dropped and comes back on the next call."""
+    import torch
+    P = pkg()
+    blocks = [fuzzgen.gen("text_mtg", 77 + i, 65536).tobytes() for i in range(6)]
+    want = [oracle_lib.raw_compress(b) for b in blocks]
+    src = torch.from_numpy(np.frombuffer(b"".join(blocks), dtype=np.uint8).copy()).cuda()
+    st = torch.cuda.Stream()
+    free0 = torch.cuda.mem_get_info()[0]
+    for rnd in range(3):
+        os.environ["SZ_KERNEL"] = "dual"
+        try:
+            with torch.cuda.stream(st):
+                dst, ol = P.compress_blocks(src, 65536, 6, stream=st)
+            st.synchronize()
+        finally:
+            os.environ.pop("SZ_KERNEL", None)
+        ln = ol.cpu().numpy()
+        out = dst.reshape(6, P.SLOT_STRIDE).cpu().numpy()
+        assert [out[i, :ln[i]].tobytes() for i in range(6)] == want
+        assert P.lib().sz_release_stream_resources(ctypes.c_void_p(st.cuda_stream)) == 0
+    del dst, ol
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)  # the 128 MiB workspace is not left behind
