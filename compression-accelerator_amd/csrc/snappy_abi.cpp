@@ -398,8 +398,47 @@ int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *
     uint8_t *d_in = static_cast<uint8_t *>(ws.buf[0]);
     uint8_t *d_out = static_cast<uint8_t *>(ws.buf[1]);
     uint32_t *d_meta = static_cast<uint32_t *>(ws.buf[2]);  // [0]=src_len [1]=out_len [2]=status
-    uint32_t meta[3] = {(uint32_t)n, 0, 0};
     SZ_HIP(hipMemcpyAsync(d_in, src, n, hipMemcpyHostToDevice, ws.stream));
+
+    // A stream of more than a few fragments: find the fragments' compressed offsets in parallel
+    // (snappy_stream_index.hip) and decode one wavefront per fragment.  Anything unusual -- a stream
+    // that was not produced in 64 KiB fragments, a malformed element -- falls through to the serial
+    // decoder below, which also produces the error code.
+    const size_t n_frag = (ulen + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE;
+    if (n_frag >= 4 && n <= 0x7fffffffull && !getenv("SZ_SERIAL_UNCOMPRESS")) {
+        size_t body = 0;
+        while (body < 5 && (static_cast<const uint8_t *>(src)[body] & 0x80))
+            body++;
+        body++;
+        const size_t off_bytes = (n_frag + 1) * sizeof(uint64_t);
+        const size_t arr_bytes = off_bytes + n_frag * 8 + 16;
+        if ((rc = ws.reserve(3, szk::stream_index_scratch_bytes(n))) || (rc = ws.reserve(4, arr_bytes)))
+            return rc;
+        uint64_t *d_off = static_cast<uint64_t *>(ws.buf[4]);
+        uint32_t *d_flen = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ws.buf[4]) + off_bytes);
+        int32_t *d_fst = reinterpret_cast<int32_t *>(d_flen + n_frag);
+        uint32_t *d_res = reinterpret_cast<uint32_t *>(d_fst + n_frag);
+        SZ_HIP(hipMemsetAsync(d_off, 0xff, off_bytes, ws.stream));  // "not found" = UINT64_MAX
+        SZ_HIP(hipMemsetAsync(d_res, 0, 8, ws.stream));
+        const uint64_t ends[2] = {body, n};
+        SZ_HIP(hipMemcpyAsync(d_off, &ends[0], 8, hipMemcpyHostToDevice, ws.stream));
+        SZ_HIP(hipMemcpyAsync(d_off + n_frag, &ends[1], 8, hipMemcpyHostToDevice, ws.stream));
+        SZ_HIP(szk::launch_stream_index(d_in, n, (uint32_t)body, ulen, ws.buf[3], d_off, d_res, ws.stream));
+        SZ_HIP(szk::launch_uncompress_packed(d_in, d_off, (uint32_t)n_frag, ulen, d_out, d_flen, d_fst, ws.stream));
+        std::vector<int32_t> fst(n_frag + 2);
+        SZ_HIP(hipMemcpyAsync(fst.data(), d_fst, (n_frag + 2) * sizeof(int32_t), hipMemcpyDeviceToHost, ws.stream));
+        SZ_HIP(hipStreamSynchronize(ws.stream));
+        bool good = fst[n_frag] == 0 && fst[n_frag + 1] == 0;  // d_res follows d_fst
+        for (size_t i = 0; good && i < n_frag; i++)
+            good = fst[i] == 0;
+        if (good) {
+            SZ_HIP(hipMemcpyAsync(dst, d_out, ulen, hipMemcpyDeviceToHost, ws.stream));
+            SZ_HIP(hipStreamSynchronize(ws.stream));
+            *out_len = ulen;
+            return SZ_OK;
+        }
+    }
+    uint32_t meta[3] = {(uint32_t)n, 0, 0};
     SZ_HIP(hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, ws.stream));
     if ((rc = sz_uncompress_blocks_hip(d_in, n, d_meta, 1, d_out, ulen, d_meta + 1,
                                        reinterpret_cast<int32_t *>(d_meta + 2), ws.stream)))

@@ -120,7 +120,10 @@ int sz_uncompress_packed_hip(const void *d_packed, const uint64_t *d_off, uint32
  * fragments, all fragments compressed on the GPU in one launch.  n < 2^32. */
 int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len);
 
-/* snappy::Uncompress on the GPU.  *out_len receives the decoded size. */
+/* snappy::Uncompress on the GPU.  *out_len receives the decoded size.  A stream of four or more
+ * 64 KiB fragments is indexed in parallel on the GPU (where does each fragment begin) and decoded
+ * one wavefront per fragment; shorter streams, and streams that were not written fragment by
+ * fragment, are decoded by a single wavefront. */
 int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len);
 
 /* snappy::GetUncompressedLength (host-side varint parse, no GPU needed). */

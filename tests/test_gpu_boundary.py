@@ -571,3 +571,84 @@ def test_release_stream_resources_and_reuse():
     del dst, ol
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)  # the 128 MiB workspace is not left behind
+
+
+def _varint(n):
+    out = bytearray()
+    while n >= 0x80:
+        out.append((n & 0x7f) | 0x80)
+        n >>= 7
+    out.append(n)
+    return bytes(out)
+
+
+def _literal(payload):
+    n = len(payload) - 1
+    if n < 60:
+        return bytes([n << 2]) + payload
+    nb = 1 if n < 256 else 2 if n < 65536 else 3 if n < (1 << 24) else 4
+    return bytes([(59 + nb) << 2]) + n.to_bytes(nb, "little") + payload
+
+
+def test_large_single_stream_takes_the_indexed_path_and_agrees_with_the_serial_decoder(monkeypatch):
+    """sz_uncompress on one stream of many fragments: fragment offsets are found in parallel
+    (snappy_stream_index.hip) and the fragments decoded one wave each; streams that are valid but not
+    made of 64 KiB fragments, and damaged streams, must come out exactly as from the serial decoder
+    (SZ_SERIAL_UNCOMPRESS=1) and the oracle."""
+    P = pkg()
+    mtg = fuzzgen.corpus("mtg")
+    rs = np.random.RandomState(99)
+    cases = {
+        "text 40 fragments + ragged tail": (mtg * 2)[:65536 * 40 + 12345],
+        "exact multiple of 64 KiB": fuzzgen.gen("lz", 5, 65536 * 8).tobytes(),
+        "incompressible": fuzzgen.corpus("random_ascii") * 9,
+        "mixed": b"".join(fuzzgen.gen(k, 300 + i, 65536).tobytes() for i, k in enumerate(("random", "text_mtg", "same", "words", "runs", "sparse", "alpha2", "periodic"))),
+    }
+    for name, data in cases.items():
+        comp = oracle_lib.raw_compress(data)
+        assert P.uncompress(comp) == data, name
+    # valid streams that no 64 KiB-fragment compressor would write
+    blob = rs.randint(0, 256, size=300000, dtype=np.uint8).tobytes()
+    odd1 = _varint(300000) + _literal(blob[:100000]) + _literal(blob[100000:100001]) + _literal(blob[100001:])
+    # copies that reach back across a 64 KiB boundary (offset 65535 at output position 70000)
+    base = rs.randint(0, 256, size=70000, dtype=np.uint8).tobytes()
+    tail = bytes(base[70000 - 65535 + i] for i in range(64))
+    odd2_data = base + tail + base[:200000 - 70064] * 3
+    odd2_data = odd2_data[:270000]
+    odd2 = _varint(len(odd2_data)) + _literal(base) + bytes([(63 << 2) | 2]) + (65535).to_bytes(2, "little") + _literal(odd2_data[70064:])
+    for name, comp, want in (("literals across boundaries", odd1, blob), ("copy across a boundary", odd2, odd2_data)):
+        assert oracle_lib.uncompress(comp) == want, name
+        assert P.uncompress(comp) == want, name
+    # damage: the verdict and the bytes must not depend on the path
+    good = oracle_lib.raw_compress((mtg * 2)[:65536 * 24 + 777])
+    for i in range(40):
+        s = bytearray(good)
+        mode = i % 4
+        if mode == 0:
+            for _ in range(3):
+                s[int(rs.randint(5, len(s)))] ^= 1 << int(rs.randint(0, 8))
+        elif mode == 1:
+            s = s[:int(rs.randint(len(s) // 2, len(s)))]
+        elif mode == 2:
+            pos = int(rs.randint(5, len(s)))
+            s[pos:pos] = bytes(rs.randint(0, 256, size=3, dtype=np.uint8))
+        else:
+            pos = int(rs.randint(5, len(s) - 10))
+            del s[pos:pos + int(rs.randint(1, 6))]
+        s = bytes(s)
+
+        def run():
+            try:
+                return ("ok", P.uncompress(s))
+            except P.SnappyHipError as e:
+                return ("err", e.code)
+        got = run()
+        monkeypatch.setenv("SZ_SERIAL_UNCOMPRESS", "1")
+        ref = run()
+        monkeypatch.delenv("SZ_SERIAL_UNCOMPRESS")
+        assert got == ref, (i, mode, got[0], ref[0])
+        try:
+            want = ("ok", oracle_lib.uncompress(s))
+        except Exception:
+            want = ("err", None)
+        assert got[0] == want[0] and (got[0] == "err" or got[1] == want[1]), (i, mode)
