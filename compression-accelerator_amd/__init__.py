@@ -29,7 +29,8 @@ ROCC_CHANNEL, ROCC_COMPRESS, ROCC_UNCOMPRESS, ROCC_SET_LENGTH = 3, 0, 1, 2
 # every symbol include/snappy_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "sz_max_compressed_length", "sz_compress_blocks_hip", "sz_compress_stream_hip", "sz_pack_stream_hip",
-    "sz_uncompress_blocks_hip", "sz_uncompress_packed_hip", "sz_compress", "sz_uncompress", "sz_get_uncompressed_length",
+    "sz_uncompress_blocks_hip", "sz_uncompress_packed_hip", "sz_uncompress_stream_work_bytes",
+    "sz_uncompress_stream_hip", "sz_compress", "sz_uncompress", "sz_get_uncompressed_length",
     "sz_rocc_cmd", "rocc_cmd", "sz_rocc_last_error", "sz_release_thread_resources",
     "sz_release_stream_resources", "sz_device_count",
     "sz_last_hip_error", "sz_strerror", "sz_version",
@@ -75,6 +76,10 @@ def lib():
     L.sz_uncompress_blocks_hip.restype = i32
     L.sz_uncompress_packed_hip.argtypes = [vp, vp, u32, u64, vp, vp, vp, vp]
     L.sz_uncompress_packed_hip.restype = i32
+    L.sz_uncompress_stream_work_bytes.argtypes = [sz, u64]
+    L.sz_uncompress_stream_work_bytes.restype = sz
+    L.sz_uncompress_stream_hip.argtypes = [vp, sz, sz, u64, vp, vp, sz, vp, vp]
+    L.sz_uncompress_stream_hip.restype = i32
     L.sz_compress.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
     L.sz_compress.restype = i32
     L.sz_uncompress.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
@@ -191,6 +196,21 @@ def uncompress_packed(packed, offsets, n_blocks, total_ulen, dst=None, stream=No
                                           _ptr(out_len), _ptr(status), _stream_handle(stream)),
            "sz_uncompress_packed_hip")
     return dst, out_len, status
+
+
+def uncompress_stream(src, n, body, ulen, dst=None, stream=None):
+    """One raw stream in HBM, fragments found and decoded in parallel; returns (dst, status3 int32[3]):
+    all zero = decoded, else fall back to uncompress_blocks with one stream.  `src` must be readable
+    8 bytes past n (allocate a little more)."""
+    import torch
+    if dst is None:
+        dst = torch.empty(ulen, dtype=torch.uint8, device=src.device)
+    wb = lib().sz_uncompress_stream_work_bytes(n, ulen)
+    work = torch.empty(wb, dtype=torch.uint8, device=src.device)
+    status3 = torch.empty(3, dtype=torch.int32, device=src.device)
+    _check(lib().sz_uncompress_stream_hip(_ptr(src), n, body, ulen, _ptr(dst), _ptr(work), wb, _ptr(status3),
+                                          _stream_handle(stream)), "sz_uncompress_stream_hip")
+    return dst, status3
 
 
 # ---------------------------------------------------------------------------- host-buffer API

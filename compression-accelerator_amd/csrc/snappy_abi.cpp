@@ -307,6 +307,34 @@ int sz_uncompress_packed_hip(const void *d_packed, const uint64_t *d_off, uint32
     return SZ_OK;
 }
 
+size_t sz_uncompress_stream_work_bytes(size_t n, uint64_t ulen)
+{
+    const size_t n_frag = (size_t)((ulen + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
+    return ((szk::stream_index_scratch_bytes(n) + 15) & ~(size_t)15) + (n_frag + 1) * sizeof(uint64_t) + n_frag * 8 + 64;
+}
+
+int sz_uncompress_stream_hip(const void *d_src, size_t n, size_t body, uint64_t ulen, void *d_dst, void *d_work,
+                             size_t work_bytes, int32_t *d_status3, void *stream)
+{
+    if (!d_src || !d_dst || !d_work || !d_status3 || n == 0 || body == 0 || body > 5 || body > n ||
+        n > 0x7fffffffull || ulen == 0 || ulen > 0xffffffffull)
+        return SZ_EINVAL;
+    if (work_bytes < sz_uncompress_stream_work_bytes(n, ulen))
+        return SZ_ENOSPC;
+    const size_t n_frag = (size_t)((ulen + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
+    uint8_t *w = static_cast<uint8_t *>(d_work);
+    const size_t idx_bytes = (szk::stream_index_scratch_bytes(n) + 15) & ~(size_t)15;
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(w + idx_bytes);
+    uint32_t *d_flen = reinterpret_cast<uint32_t *>(d_off + n_frag + 1);
+    int32_t *d_fst = reinterpret_cast<int32_t *>(d_flen + n_frag);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t *d_res = reinterpret_cast<uint32_t *>(d_status3);
+    SZ_HIP(szk::launch_stream_index(d_src, n, (uint32_t)body, ulen, w, d_off, d_res, s));
+    SZ_HIP(szk::launch_uncompress_packed(d_src, d_off, (uint32_t)n_frag, ulen, d_dst, d_flen, d_fst, s));
+    SZ_HIP(szk::launch_count_failed(d_fst, (uint32_t)n_frag, d_res, s));
+    return SZ_OK;
+}
+
 /* --------------------------------------------------------------------- host-buffer API */
 
 int sz_get_uncompressed_length(const void *src, size_t n, size_t *result)
@@ -410,27 +438,16 @@ int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *
         while (body < 5 && (static_cast<const uint8_t *>(src)[body] & 0x80))
             body++;
         body++;
-        const size_t off_bytes = (n_frag + 1) * sizeof(uint64_t);
-        const size_t arr_bytes = off_bytes + n_frag * 8 + 16;
-        if ((rc = ws.reserve(3, szk::stream_index_scratch_bytes(n))) || (rc = ws.reserve(4, arr_bytes)))
+        const size_t work = sz_uncompress_stream_work_bytes(n, ulen);
+        if ((rc = ws.reserve(3, work)))
             return rc;
-        uint64_t *d_off = static_cast<uint64_t *>(ws.buf[4]);
-        uint32_t *d_flen = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ws.buf[4]) + off_bytes);
-        int32_t *d_fst = reinterpret_cast<int32_t *>(d_flen + n_frag);
-        uint32_t *d_res = reinterpret_cast<uint32_t *>(d_fst + n_frag);
-        SZ_HIP(hipMemsetAsync(d_off, 0xff, off_bytes, ws.stream));  // "not found" = UINT64_MAX
-        SZ_HIP(hipMemsetAsync(d_res, 0, 8, ws.stream));
-        const uint64_t ends[2] = {body, n};
-        SZ_HIP(hipMemcpyAsync(d_off, &ends[0], 8, hipMemcpyHostToDevice, ws.stream));
-        SZ_HIP(hipMemcpyAsync(d_off + n_frag, &ends[1], 8, hipMemcpyHostToDevice, ws.stream));
-        SZ_HIP(szk::launch_stream_index(d_in, n, (uint32_t)body, ulen, ws.buf[3], d_off, d_res, ws.stream));
-        SZ_HIP(szk::launch_uncompress_packed(d_in, d_off, (uint32_t)n_frag, ulen, d_out, d_flen, d_fst, ws.stream));
-        std::vector<int32_t> fst(n_frag + 2);
-        SZ_HIP(hipMemcpyAsync(fst.data(), d_fst, (n_frag + 2) * sizeof(int32_t), hipMemcpyDeviceToHost, ws.stream));
+        int32_t *d_st = reinterpret_cast<int32_t *>(d_meta);  // 3 words
+        if ((rc = sz_uncompress_stream_hip(d_in, n, body, ulen, d_out, ws.buf[3], work, d_st, ws.stream)))
+            return rc;
+        int32_t st3[3] = {1, 1, 1};
+        SZ_HIP(hipMemcpyAsync(st3, d_st, sizeof(st3), hipMemcpyDeviceToHost, ws.stream));
         SZ_HIP(hipStreamSynchronize(ws.stream));
-        bool good = fst[n_frag] == 0 && fst[n_frag + 1] == 0;  // d_res follows d_fst
-        for (size_t i = 0; good && i < n_frag; i++)
-            good = fst[i] == 0;
+        const bool good = st3[0] == 0 && st3[1] == 0 && st3[2] == 0;
         if (good) {
             SZ_HIP(hipMemcpyAsync(dst, d_out, ulen, hipMemcpyDeviceToHost, ws.stream));
             SZ_HIP(hipStreamSynchronize(ws.stream));

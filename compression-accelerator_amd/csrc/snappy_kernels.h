@@ -50,11 +50,13 @@ hipError_t launch_uncompress_packed(const void *d_packed, const uint64_t *d_off,
                                     uint64_t total_ulen, void *d_dst, uint32_t *d_out_len,
                                     int32_t *d_status, hipStream_t stream);
 
-// Fragment index of one raw stream (snappy_stream_index.hip): fills d_off[1 .. n_frag-1] with the
-// compressed offsets of the 64 KiB output boundaries, d_result[0] = 0 if the stream parses cleanly,
-// d_result[1] = 0 if every boundary falls between two elements.
+// Fragment index of one raw stream (snappy_stream_index.hip): fills d_off[0 .. n_frag] with the
+// compressed offsets of the 64 KiB output boundaries (UINT64_MAX where none was found),
+// d_result[0] = 0 if the stream parses cleanly, d_result[1] = 0 if every boundary falls between two
+// elements, d_result[2] = 0; launch_count_failed adds the fragments with a non-zero status to [2].
 size_t stream_index_scratch_bytes(uint64_t n);
 hipError_t launch_stream_index(const void *d_in, uint64_t n, uint32_t body, uint64_t ulen, void *d_scratch,
                                uint64_t *d_off, uint32_t *d_result, hipStream_t stream);
+hipError_t launch_count_failed(const int32_t *d_status, uint32_t n_frag, uint32_t *d_result, hipStream_t stream);
 
 }  // namespace szk

@@ -223,6 +223,28 @@ __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__
     }
 }
 
+// off[0] = body, off[n_frag] = n, everything between "not found"; result[0..2] = 0
+__global__ __launch_bounds__(256) void stream_index_init_kernel(unsigned long long *__restrict__ off, uint32_t n_frag,
+                                                                uint32_t body, uint32_t n, uint32_t *__restrict__ result)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i <= n_frag)
+        off[i] = i == 0 ? body : (i == n_frag ? n : ~0ull);
+    if (i < 3)
+        result[i] = 0;
+}
+
+// result[2] += number of fragments whose decode failed (status != 0)
+__global__ __launch_bounds__(256) void count_failed_kernel(const int32_t *__restrict__ status, uint32_t n_frag,
+                                                           uint32_t *__restrict__ result)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool bad = i < n_frag && status[i] != 0;
+    const uint64_t m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicAdd(result + 2, (uint32_t)__builtin_popcountll(m));
+}
+
 // ------------------------------------------------------------------------------- launcher
 size_t stream_index_scratch_bytes(uint64_t n)
 {
@@ -231,21 +253,31 @@ size_t stream_index_scratch_bytes(uint64_t n)
 }
 
 // d_in: the whole raw stream (n < 2^31 bytes, readable up to n + 8), body = size of its preamble,
-// ulen = the decoded size it announces.  Fills d_off[1 .. n_frag-1] (d_off[0] and d_off[n_frag] are
-// the caller's: body and n) and d_result[0..1] = {parse status, boundary flags}; d_off entries that
-// are not found keep the caller's initial value.
+// ulen = the decoded size it announces, n_frag = ceil(ulen / 64 KiB).  Fills d_off[0 .. n_frag]
+// (boundaries that are not found stay UINT64_MAX) and d_result[0..1] = {parse status, boundary
+// flags}; d_result[2] := 0 (see launch_count_failed).
 hipError_t launch_stream_index(const void *d_in, uint64_t n, uint32_t body, uint64_t ulen, void *d_scratch,
                                uint64_t *d_off, uint32_t *d_result, hipStream_t stream)
 {
     const uint32_t n_seg = (uint32_t)((n + kSeg - 1) / kSeg);
+    const uint32_t n_frag = (uint32_t)((ulen + kMaxBlock - 1) / kMaxBlock);
     uint2 *maps = static_cast<uint2 *>(d_scratch);
     uint2 *entries = maps + (size_t)n_seg * 64;
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    unsigned long long *off = reinterpret_cast<unsigned long long *>(d_off);
+    hipLaunchKernelGGL(stream_index_init_kernel, dim3(n_frag / 256 + 1), dim3(256), 0, stream, off, n_frag, body,
+                       (uint32_t)n, d_result);
     hipLaunchKernelGGL(stream_segment_maps_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, n_seg, maps);
     hipLaunchKernelGGL(stream_resolve_kernel, dim3(1), dim3(64), 0, stream, in, (uint32_t)n, body, (uint32_t)ulen,
                        n_seg, maps, entries, d_result);
     hipLaunchKernelGGL(stream_boundaries_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, (uint32_t)ulen,
-                       n_seg, entries, reinterpret_cast<unsigned long long *>(d_off), d_result + 1);
+                       n_seg, entries, off, d_result + 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_failed(const int32_t *d_status, uint32_t n_frag, uint32_t *d_result, hipStream_t stream)
+{
+    hipLaunchKernelGGL(count_failed_kernel, dim3((n_frag + 255) / 256), dim3(256), 0, stream, d_status, n_frag, d_result);
     return hipGetLastError();
 }
 

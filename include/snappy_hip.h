@@ -114,6 +114,21 @@ int sz_uncompress_packed_hip(const void *d_packed, const uint64_t *d_off, uint32
                              uint64_t total_ulen, void *d_dst, uint32_t *d_out_len, int32_t *d_status,
                              void *stream);
 
+/* ONE raw stream (preamble + elements) resident in HBM, decoded in parallel without side
+ * information: the compressed offsets of its 64 KiB fragments are found on the GPU (64 hypothetical
+ * parses per 16 KiB segment, then the true one through their maps), then every fragment is decoded by
+ * its own wavefront.  body = size of the varint preamble (1..5), ulen = the decoded size it
+ * announces (sz_get_uncompressed_length on the first bytes), n < 2^31; d_src must be readable up to
+ * n + 8; d_dst holds ulen bytes; d_work holds sz_uncompress_stream_work_bytes(n, ulen).
+ * Asynchronous.  d_status3[0..2] = {the stream does not parse, an element straddles a 64 KiB output
+ * boundary, number of fragments that failed to decode}: all zero = d_dst is the decoded stream.
+ * Otherwise the stream is malformed OR simply was not written in 64 KiB fragments (every stock
+ * Snappy compressor does write them): decode it with sz_uncompress_blocks_hip as one stream, which
+ * also tells the two apart. */
+size_t sz_uncompress_stream_work_bytes(size_t n, uint64_t ulen);
+int sz_uncompress_stream_hip(const void *d_src, size_t n, size_t body, uint64_t ulen, void *d_dst,
+                             void *d_work, size_t work_bytes, int32_t *d_status3, void *stream);
+
 /* ---- host-buffer convenience API (what the snappy:: facade and the RoCC surface call) ---- */
 
 /* Exactly the bytes of snappy::Compress(src, n): varint32(n) + bodies of consecutive 64 KiB

@@ -652,3 +652,53 @@ def test_large_single_stream_takes_the_indexed_path_and_agrees_with_the_serial_d
         except Exception:
             want = ("err", None)
         assert got[0] == want[0] and (got[0] == "err" or got[1] == want[1]), (i, mode)
+
+
+def test_device_stream_decode_without_side_information():
+    """sz_uncompress_stream_hip: one raw stream in HBM -> fragment index on the GPU -> one wave per
+    fragment; all three status words zero exactly when the stream is made of 64 KiB fragments and intact."""
+    import torch
+    P = pkg()
+    mtg = fuzzgen.corpus("mtg")
+    data = (mtg * 3)[:65536 * 100 + 4321]
+    comp = oracle_lib.raw_compress(data)
+    body = 4
+    assert P.uncompressed_length(comp) == len(data)
+
+    def run(c, ulen):
+        buf = torch.zeros(len(c) + 64, dtype=torch.uint8, device="cuda")  # readable past n
+        buf[:len(c)] = torch.from_numpy(np.frombuffer(c, dtype=np.uint8).copy()).cuda()
+        out, st = P.uncompress_stream(buf, len(c), body, ulen)
+        torch.cuda.synchronize()
+        return out, st.cpu().numpy().tolist()
+
+    out, st = run(comp, len(data))
+    assert st == [0, 0, 0]
+    assert out.cpu().numpy().tobytes() == data
+    # flipped bits: either reported, or (a payload byte, a still-valid tag) decoded exactly as the oracle does
+    rs = np.random.RandomState(17)
+    reported = 0
+    for _ in range(12):
+        s = bytearray(comp)
+        for _ in range(2):
+            s[int(rs.randint(body, len(s)))] ^= 1 << int(rs.randint(0, 8))
+        out, st = run(bytes(s), len(data))
+        try:
+            want = oracle_lib.uncompress(bytes(s))
+        except ValueError:
+            want = None
+        if st == [0, 0, 0]:
+            assert want is not None and out.cpu().numpy().tobytes() == want
+        else:
+            reported += 1
+    assert reported >= 1
+    # a valid stream that is not fragment-aligned: flagged as such (parse fine, boundary flag set)
+    blob = np.random.RandomState(3).randint(0, 256, size=300000, dtype=np.uint8).tobytes()
+    odd = _varint(300000) + _literal(blob[:100000]) + _literal(blob[100000:])
+    buf_body = len(_varint(300000))
+    bufc = torch.zeros(len(odd) + 64, dtype=torch.uint8, device="cuda")
+    bufc[:len(odd)] = torch.from_numpy(np.frombuffer(odd, dtype=np.uint8).copy()).cuda()
+    out, st = P.uncompress_stream(bufc, len(odd), buf_body, 300000)
+    torch.cuda.synchronize()
+    st = st.cpu().numpy().tolist()
+    assert st[0] == 0 and st[1] != 0
