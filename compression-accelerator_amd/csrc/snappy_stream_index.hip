@@ -126,35 +126,53 @@ __global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__res
                                                             const uint2 *__restrict__ maps,
                                                             uint2 *__restrict__ entries, uint32_t *__restrict__ result)
 {
+    // The walk is a chain of dependent look-ups; straight from global memory each costs a memory
+    // latency.  The maps of 64 segments (32 KiB) are therefore staged in LDS with one burst of
+    // coalesced loads and stepped through from there.
+    __shared__ uint2 lmap[64 * 64];
     const uint32_t lane = threadIdx.x;
     uint32_t p = body, out = 0;
     bool ok = true;
-    for (uint32_t s = 0; s < n_seg && ok; s++) {
-        const uint32_t seg_base = s * kSeg;
-        const uint32_t seg_end = seg_base + kSeg < n ? seg_base + kSeg : n;
-        if (p >= seg_end) {
+    for (uint32_t s0 = 0; s0 < n_seg && ok; s0 += 64) {
+        const uint32_t cnt = n_seg - s0 < 64 ? n_seg - s0 : 64;
+        bool staged = false;  // on first use: a run of long literals (incompressible data) never looks a map up
+        for (uint32_t k = 0; k < cnt && ok; k++) {
+            const uint32_t s = s0 + k;
+            const uint32_t seg_base = s * kSeg;
+            const uint32_t seg_end = seg_base + kSeg < n ? seg_base + kSeg : n;
+            if (p >= seg_end) {
+                if (lane == 0)
+                    entries[s] = make_uint2(kBad, 0);
+                continue;
+            }
             if (lane == 0)
-                entries[s] = make_uint2(kBad, 0);
-            continue;
-        }
-        if (lane == 0)
-            entries[s] = make_uint2(p, out);
-        if (p - seg_base < 64) {
-            const uint2 m = maps[(size_t)s * 64 + (p - seg_base)];
-            const uint32_t ex = uni(m.x), os = uni(m.y);
-            ok = ex != kBad;
-            p = ex;
-            out += os;
-        } else {  // entered far into the segment (after a long literal): parse its rest here
-            while (ok && p < seg_end) {
-                uint32_t E, O;
-                window_map(in, p, seg_end, n, lane, E, O);
-                const uint32_t e = lane_get(E, 0), o = lane_get(O, 0);
-                ok = e != kBad;
-                out += o;
-                p += e;
+                entries[s] = make_uint2(p, out);
+            if (p - seg_base < 64) {
+                if (!staged) {
+                    const u32x4 *g = reinterpret_cast<const u32x4 *>(maps + (size_t)s0 * 64);
+                    u32x4 *l = reinterpret_cast<u32x4 *>(lmap);
+                    for (uint32_t i = lane; i < cnt * 32; i += 64)  // 32 x 16 bytes per segment
+                        l[i] = g[i];
+                    __syncthreads();
+                    staged = true;
+                }
+                const uint2 m = lmap[k * 64 + (p - seg_base)];
+                const uint32_t ex = uni(m.x), os = uni(m.y);
+                ok = ex != kBad;
+                p = ex;
+                out += os;
+            } else {  // entered far into the segment (after a long literal): parse its rest here
+                while (ok && p < seg_end) {
+                    uint32_t E, O;
+                    window_map(in, p, seg_end, n, lane, E, O);
+                    const uint32_t e = lane_get(E, 0), o = lane_get(O, 0);
+                    ok = e != kBad;
+                    out += o;
+                    p += e;
+                }
             }
         }
+        __syncthreads();
     }
     ok = ok && p == n && out == ulen;
     if (lane == 0)
