@@ -5,7 +5,7 @@
 //
 // The format has no index: where an element starts is known only after the element before it.  But
 // where an element WOULD end if it started at a given byte is a local question, so:
-//   1. segment maps (one wave per 16 KiB segment of the compressed bytes): 64 hypothetical parses run
+//   1. segment maps (one wave per 16-64 KiB segment of the compressed bytes): 64 hypothetical parses run
 //      at once, one per lane, starting at the first 64 bytes of the segment; per window of 64 bytes
 //      every lane decodes "its" tag, pointer jumping (ds_bpermute) turns that into "where does a
 //      chain entering the window at lane l leave it, and how many bytes did it produce", and each
@@ -22,7 +22,9 @@
 
 namespace szk {
 
-static constexpr uint32_t kSeg = 16384;  // compressed bytes per segment
+// compressed bytes per segment: 16, 32 or 64 KiB, chosen per stream (small streams want many segments
+// for the parallel passes, large ones few for the serial one)
+__host__ __device__ static inline uint32_t seg_shift_for(uint64_t n) { return n < (64ull << 20) ? 14u : (n < (256ull << 20) ? 15u : 16u); }
 static constexpr uint32_t kBad = 0xffffffffu;
 
 // The element that would start at byte p < n: compressed size including payload, produced bytes;
@@ -93,8 +95,10 @@ __device__ __forceinline__ void window_map(const uint8_t *__restrict__ in, uint3
 
 // ---- 1. segment maps
 __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *__restrict__ in, uint32_t n,
-                                                                 uint32_t n_seg, uint2 *__restrict__ maps)
+                                                                 uint32_t n_seg, uint32_t seg_shift,
+                                                                 uint2 *__restrict__ maps)
 {
+    const uint32_t kSeg = 1u << seg_shift;
     const uint32_t lane = threadIdx.x, s = blockIdx.x;
     if (s >= n_seg)
         return;
@@ -122,10 +126,11 @@ __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *
 // entries[s] = (position, bytes produced) where the true parse enters segment s, (kBad, 0) if it
 // skips the segment inside a literal; result[0] = 0 if the stream parses cleanly to its end.
 __global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t body,
-                                                            uint32_t ulen, uint32_t n_seg,
+                                                            uint32_t ulen, uint32_t n_seg, uint32_t seg_shift,
                                                             const uint2 *__restrict__ maps,
                                                             uint2 *__restrict__ entries, uint32_t *__restrict__ result)
 {
+    const uint32_t kSeg = 1u << seg_shift;
     // The walk is a chain of dependent look-ups; straight from global memory each costs a memory
     // latency.  The maps of 64 segments (32 KiB) are therefore staged in LDS with one burst of
     // coalesced loads and stepped through from there.
@@ -183,10 +188,12 @@ __global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__res
 // off[m] := compressed offset of the element that starts at output position m * 64 KiB (0 < m < number
 // of fragments); flag |= 2 if an element straddles such a position, |= 1 on a malformed element.
 __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t ulen,
-                                                               uint32_t n_seg, const uint2 *__restrict__ entries,
+                                                               uint32_t n_seg, uint32_t seg_shift,
+                                                               const uint2 *__restrict__ entries,
                                                                unsigned long long *__restrict__ off,
                                                                uint32_t *__restrict__ flag)
 {
+    const uint32_t kSeg = 1u << seg_shift;
     const uint32_t lane = threadIdx.x, s = blockIdx.x;
     if (s >= n_seg)
         return;
@@ -266,7 +273,8 @@ __global__ __launch_bounds__(256) void count_failed_kernel(const int32_t *__rest
 // ------------------------------------------------------------------------------- launcher
 size_t stream_index_scratch_bytes(uint64_t n)
 {
-    const size_t n_seg = (size_t)((n + kSeg - 1) / kSeg);
+    const uint64_t seg = 1ull << seg_shift_for(n);
+    const size_t n_seg = (size_t)((n + seg - 1) / seg);
     return n_seg * 64 * sizeof(uint2) + n_seg * sizeof(uint2) + 64;
 }
 
@@ -277,7 +285,8 @@ size_t stream_index_scratch_bytes(uint64_t n)
 hipError_t launch_stream_index(const void *d_in, uint64_t n, uint32_t body, uint64_t ulen, void *d_scratch,
                                uint64_t *d_off, uint32_t *d_result, hipStream_t stream)
 {
-    const uint32_t n_seg = (uint32_t)((n + kSeg - 1) / kSeg);
+    const uint32_t seg_shift = seg_shift_for(n);
+    const uint32_t n_seg = (uint32_t)((n + (1ull << seg_shift) - 1) >> seg_shift);
     const uint32_t n_frag = (uint32_t)((ulen + kMaxBlock - 1) / kMaxBlock);
     uint2 *maps = static_cast<uint2 *>(d_scratch);
     uint2 *entries = maps + (size_t)n_seg * 64;
@@ -285,11 +294,11 @@ hipError_t launch_stream_index(const void *d_in, uint64_t n, uint32_t body, uint
     unsigned long long *off = reinterpret_cast<unsigned long long *>(d_off);
     hipLaunchKernelGGL(stream_index_init_kernel, dim3(n_frag / 256 + 1), dim3(256), 0, stream, off, n_frag, body,
                        (uint32_t)n, d_result);
-    hipLaunchKernelGGL(stream_segment_maps_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, n_seg, maps);
+    hipLaunchKernelGGL(stream_segment_maps_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, n_seg, seg_shift, maps);
     hipLaunchKernelGGL(stream_resolve_kernel, dim3(1), dim3(64), 0, stream, in, (uint32_t)n, body, (uint32_t)ulen,
-                       n_seg, maps, entries, d_result);
+                       n_seg, seg_shift, maps, entries, d_result);
     hipLaunchKernelGGL(stream_boundaries_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, (uint32_t)ulen,
-                       n_seg, entries, off, d_result + 1);
+                       n_seg, seg_shift, entries, off, d_result + 1);
     return hipGetLastError();
 }
 
