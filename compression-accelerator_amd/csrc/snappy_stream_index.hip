@@ -18,13 +18,23 @@
 //      means the stream was not produced fragment by fragment: the caller then decodes serially.
 // Streams of every stock Snappy compressor (64 KiB fragments) qualify.  Nothing here moves payload
 // bytes; the bound is instruction issue of the tag decode (about 100 instructions per 64 bytes).
+#include <stdlib.h>
+
 #include "wave_utils.h"
 
 namespace szk {
 
 // compressed bytes per segment: 16, 32 or 64 KiB, chosen per stream (small streams want many segments
 // for the parallel passes, large ones few for the serial one)
-__host__ __device__ static inline uint32_t seg_shift_for(uint64_t n) { return n < (64ull << 20) ? 14u : (n < (256ull << 20) ? 15u : 16u); }
+static inline uint32_t seg_shift_for(uint64_t n)
+{
+    if (const char *e = getenv("SZ_TEST_SEG_SHIFT")) {  // test hook: every segment size on small streams
+        const int v = atoi(e);
+        if (v >= 14 && v <= 16)
+            return (uint32_t)v;
+    }
+    return n < (64ull << 20) ? 14u : (n < (256ull << 20) ? 15u : 16u);
+}
 static constexpr uint32_t kBad = 0xffffffffu;
 
 // The element that would start at byte p < n: compressed size including payload, produced bytes;
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256) void count_failed_kernel(const int32_t *__rest
 // ------------------------------------------------------------------------------- launcher
 size_t stream_index_scratch_bytes(uint64_t n)
 {
-    const uint64_t seg = 1ull << seg_shift_for(n);
+    const uint64_t seg = 1ull << 14;  // sized for the smallest segments (the choice may be overridden in tests)
     const size_t n_seg = (size_t)((n + seg - 1) / seg);
     return n_seg * 64 * sizeof(uint2) + n_seg * sizeof(uint2) + 64;
 }
