@@ -33,6 +33,10 @@
  * one-wave kernel), so make one warm-up call before capturing a graph.  Which kernel runs is
  * chosen per launch from a sample of the data; environment SZ_KERNEL=single|dual forces one
  * (same output bytes either way).
+ *
+ * Environment (all optional, read per call): SZ_KERNEL=single|dual forces a compress kernel;
+ * SZ_SERIAL_UNCOMPRESS=1 makes sz_uncompress skip the parallel fragment index (single-wavefront
+ * decode of the whole stream); SZ_TEST_GEN_INIT, SZ_TEST_SEG_SHIFT are hooks of the test-suite.
  */
 #ifndef SNAPPY_HIP_H
 #define SNAPPY_HIP_H
