@@ -164,3 +164,24 @@ def test_unaligned_buffers_and_odd_strides():
             want = oracle_lib.raw_compress(b)
             assert ol[i] == len(want) and out[base:base + ol[i]].tobytes() == want, (src_off, i, lens[i])
             assert (out[base + ol[i]:base + dst_stride] == 0xA5).all(), "wrote past the end of block %d" % i
+
+
+def test_fixed_size_small_blocks_have_their_own_kernel():
+    """Fixed blocks of <= 8 KiB (pages) go through compress_small_blocks_kernel (dynamic LDS table of
+    2*T bytes), larger fixed blocks through the usual kernels: same bytes as the oracle for every
+    table size 256 .. 16384 and every generator."""
+    import torch
+    P = pkg()
+    for bs in (15, 16, 100, 256, 257, 1000, 1024, 4096, 5000, 8192, 12345, 16384):
+        blocks = []
+        for i, kind in enumerate(fuzzgen.KINDS * 2):
+            blocks.append(fuzzgen.gen(kind, 7000 + 31 * bs + i, bs).tobytes())
+        nb = len(blocks)
+        src = torch.from_numpy(np.frombuffer(b"".join(blocks), dtype=np.uint8).copy()).cuda()
+        stride = (int(P.max_compressed_length(bs)) + 8 + 15) // 16 * 16
+        dst, ol = P.compress_blocks(src, bs, nb, dst_stride=stride)
+        torch.cuda.synchronize()
+        ln = ol.cpu().numpy()
+        out = dst.reshape(nb, stride).cpu().numpy()
+        for i in range(nb):
+            _assert_same(out[i, :ln[i]].tobytes(), oracle_lib.raw_compress(blocks[i]), "bs=%d block %d" % (bs, i))
