@@ -438,9 +438,14 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         bool first_scan = !kLean;  // pv[] belongs to the scan that starts at 1
         PROF_DECL
         PROF_START();
+        // (every trip of this loop moves P forward or ends it; the cap turns a state that does neither
+        // -- memory that does not hold what this wave wrote -- into an error marker instead of a hang)
+        uint32_t trips = 0;
         for (;;) {
-            if (poisoned)
+            if (poisoned || ++trips > 2u * kMaxBlock) {
+                poisoned = true;
                 break;
+            }
 #ifdef SZ_ABLATION
             if (flags & 0x200u)  // timing ablation: no match finding at all (one literal)
                 break;
