@@ -991,9 +991,19 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
     if (wave >= 1)
         gen = uni(scratch_gen[my_slot]);
     for (;;) {
+        // One queue for the whole grid: faster waves take more blocks.  The counter's address goes
+        // through VGPRs on purpose.  With the address as an SGPR base, a build in which `select` was
+        // spilled (v_writelane at kernel start, v_readlane + s_nop 4 right before the atomic) hung
+        // every wave of the grid at its second pop on gfx950, while builds that kept the pointer in
+        // SGPRs ran: a reload of a spilled pointer must not feed a memory instruction's scalar base
+        // (tests/test_abi.py scans the kernel's ISA for that pattern).
         uint32_t b = 0;
-        if (lane == 0)
-            b = atomicAdd(&select[2], 1u);  // one queue for the whole grid: faster waves take more blocks
+        if (lane == 0) {
+            uint64_t qa = (uint64_t)(uintptr_t)(select + 2);
+            uint32_t qlo = (uint32_t)qa, qhi = (uint32_t)(qa >> 32);
+            asm volatile("" : "+v"(qlo), "+v"(qhi));
+            b = atomicAdd(reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)qhi << 32) | qlo)), 1u);
+        }
         b = uni(b);
         if (b >= n_blocks)
             break;

@@ -98,3 +98,38 @@ def test_reference_drivers_build_unchanged(tmp_path):
     build_util.cc(os.path.join(REF, "tests", "compression.c"), str(tmp_path / "c1"), force_shim=True)
     build_util.cxx(os.path.join(REF, "tests", "swcompression.cc"), str(tmp_path / "c2"))
     build_util.cxx(os.path.join(REF, "workloads", "snappy", "overlay", "root", "compress.cc"), str(tmp_path / "c3"))
+
+
+def _isa_of(src, tmp_path):
+    out = os.path.join(str(tmp_path), os.path.basename(src) + ".s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           "-I" + os.path.join(build_util.ROOT, "include"), "-I" + os.path.dirname(src),
+                           "-S", "--cuda-device-only", src, "-o", out])
+    with open(out) as f:
+        return f.read().splitlines()
+
+
+def test_no_reloaded_spill_feeds_a_memory_instruction_scalar_base(tmp_path):
+    """gfx950 hazard met in round 1: a kernel-argument pointer that the compiler had spilled to a VGPR
+    lane and reloaded with v_readlane + s_nop 4 right in front of `global_atomic_add ... s[N:N+1]` hung
+    every wave of the grid; the same kernel with the pointer still in SGPRs ran.  The persistent
+    multi-wave kernel therefore hands its queue counter to the atomic through VGPRs, and this test
+    scans the ISA of every kernel for the pattern (v_readlane writing the low half of an SGPR pair that
+    a vector-memory instruction uses as its scalar base within the next dozen instructions)."""
+    csrc = os.path.join(build_util.ROOT, "compression-accelerator_amd", "csrc")
+    vmem = re.compile(r"^\s*(global|flat|buffer|scratch)_\w+\s.*\bs\[(\d+):(\d+)\]")
+    offenders = []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith(".hip"):
+            continue
+        lines = [l for l in _isa_of(os.path.join(csrc, name), tmp_path) if l.strip() and not l.lstrip().startswith(";")]
+        for i, l in enumerate(lines):
+            m = vmem.match(l)
+            if not m:
+                continue
+            lo = "s%s," % m.group(2)
+            for j in range(max(0, i - 12), i):
+                if "v_readlane_b32 " + lo in lines[j]:
+                    offenders.append("%s: %s  <-  %s" % (name, l.strip(), lines[j].strip()))
+                    break
+    assert not offenders, "\n".join(offenders)
