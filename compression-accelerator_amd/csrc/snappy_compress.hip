@@ -992,11 +992,10 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
         gen = uni(scratch_gen[my_slot]);
     for (;;) {
         // One queue for the whole grid: faster waves take more blocks.  The counter's address goes
-        // through VGPRs on purpose.  With the address as an SGPR base, a build in which `select` was
-        // spilled (v_writelane at kernel start, v_readlane + s_nop 4 right before the atomic) hung
-        // every wave of the grid at its second pop on gfx950, while builds that kept the pointer in
-        // SGPRs ran: a reload of a spilled pointer must not feed a memory instruction's scalar base
-        // (tests/test_abi.py scans the kernel's ISA for that pattern).
+        // through VGPRs on purpose: experimental builds of this kernel that hung had `select` spilled
+        // to a VGPR lane and reloaded (v_readlane + s_nop 4) right before the atomic's scalar base;
+        // that was not the whole story, but the pattern is kept out of the
+        // kernels (tests/test_abi.py scans their ISA for it).
         uint32_t b = 0;
         if (lane == 0) {
             uint64_t qa = (uint64_t)(uintptr_t)(select + 2);

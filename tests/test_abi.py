@@ -110,12 +110,13 @@ def _isa_of(src, tmp_path):
 
 
 def test_no_reloaded_spill_feeds_a_memory_instruction_scalar_base(tmp_path):
-    """gfx950 hazard met in round 1: a kernel-argument pointer that the compiler had spilled to a VGPR
-    lane and reloaded with v_readlane + s_nop 4 right in front of `global_atomic_add ... s[N:N+1]` hung
-    every wave of the grid; the same kernel with the pointer still in SGPRs ran.  The persistent
-    multi-wave kernel therefore hands its queue counter to the atomic through VGPRs, and this test
-    scans the ISA of every kernel for the pattern (v_readlane writing the low half of an SGPR pair that
-    a vector-memory instruction uses as its scalar base within the next dozen instructions)."""
+    """Suspect met in round 1: experimental builds of the multi-wave kernel that hung the grid had a
+    kernel-argument pointer spilled to a VGPR lane and reloaded with v_readlane + s_nop 4 right in
+    front of `global_atomic_add ... s[N:N+1]`; builds with the pointer still in SGPRs ran.  It was not
+    the whole cause, but the pattern is kept out: the persistent kernel hands
+    its queue counter to the atomic through VGPRs, and this test scans the ISA of every kernel for a
+    v_readlane that writes the low half of an SGPR pair which a vector-memory instruction uses as its
+    scalar base within the next dozen instructions."""
     csrc = os.path.join(build_util.ROOT, "compression-accelerator_amd", "csrc")
     vmem = re.compile(r"^\s*(global|flat|buffer|scratch)_\w+\s.*\bs\[(\d+):(\d+)\]")
     offenders = []
