@@ -23,6 +23,12 @@ def _gpu_present():
 
 
 def pytest_collection_modifyitems(config, items):
+    # A GPU kernel that never finishes would otherwise hold the whole run (and the GPU box) until an
+    # outer limit: every GPU test gets a wall-clock limit; method "thread" because the main thread
+    # sits inside a HIP call then (the process is ended with a traceback of where).
+    for item in items:
+        if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(180, method="thread"))
     # -m gpu on a box without a GPU should report skips, not crash the session at import.
     if _gpu_present():
         return
