@@ -943,15 +943,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         return;
     const uint32_t n = block_length(in_len, total_len, in_stride, b);
     if (n > kMaxBlock) {  // caller error: flagged, nothing written
-        if (lane == 0)
-            out_len[b] = 0xffffffffu;
+        out_len[b] = 0xffffffffu;  // (every lane, same address, same value: see the note at the dual kernel)
         return;
     }
     const HashTab<true> tab{lds_tab, nullptr, 0u, nullptr};
     const uint32_t op = compress_one_block<64, false>(tab, src + (uint64_t)b * in_stride, n,
                                                dst + (uint64_t)b * dst_stride, flags, lane);
-    if (lane == 0)
-        out_len[b] = op;  // (a9)
+    out_len[b] = op;  // (a9) every lane, same address, same value
 }
 
 // Multi-wave ("dual") kernel: workgroups of kGroupWaves independent wavefronts, each compressing its
@@ -1008,8 +1006,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
             break;
         const uint32_t n = block_length(in_len, total_len, in_stride, b);
         if (n > kMaxBlock) {
-            if (lane == 0)
-                out_len[b] = 0xffffffffu;
+            out_len[b] = 0xffffffffu;
             continue;
         }
         uint32_t op;
@@ -1028,8 +1025,12 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
             op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
         }
-        if (lane == 0)
-            out_len[b] = op;
+        // (a9) Written by every lane -- same address, same value, one transaction -- not by lane 0
+        // alone: builds of this kernel in which the compiler merged the two lane-0 stores of this
+        // loop into one tail with a per-lane address hung the whole grid on gfx950 (every wave stalled
+        // at the end of its first block, its output written, its length not); with uniform stores the
+        // same source ran.  DESIGN.md section 7.
+        out_len[b] = op;
     }
     if (wave >= 1 && lane == 0)
         scratch_gen[my_slot] = gen;
@@ -1052,8 +1053,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
     const HashTab<true> tab{dyn_tab, nullptr, 0u, nullptr};
     const uint32_t op = compress_one_block<0, true>(tab, src + (uint64_t)b * block_bytes, block_bytes,
                                                     dst + (uint64_t)b * dst_stride, flags, lane);
-    if (lane == 0)
-        out_len[b] = op;  // (a9)
+    out_len[b] = op;  // (a9) every lane, same address, same value
 }
 
 // ------------------------------------------------------------------------------ launchers
