@@ -22,7 +22,7 @@
 namespace {
 
 // Multi-wave kernel workspace: one per (device, stream), created on first use and kept for the life
-// of the process (128 MiB on MI355X: 2 048 tagged tables).  SZ_KERNEL=single disables the dual kernel.
+// of the process (64 MiB on MI355X: 2 048 tables of 32 KiB).  SZ_KERNEL=single disables the dual kernel.
 std::mutex g_dual_mutex;
 std::map<std::pair<int, hipStream_t>, szk::DualScratch> g_dual;
 
@@ -52,7 +52,7 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
     auto it = g_dual.find(key);
     if (it != g_dual.end())
         return finish(it->second);
-    szk::DualScratch sc{nullptr, nullptr, nullptr, 0, 0, mode == 2 ? szk::kDualAlways : szk::kDualAuto};
+    szk::DualScratch sc{nullptr, nullptr, 0, 0, mode == 2 ? szk::kDualAlways : szk::kDualAuto};
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
@@ -62,19 +62,13 @@ const szk::DualScratch *dual_scratch_for(hipStream_t stream)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
         sc.n_slots = 4u * (uint32_t)cus;  // four workgroups per CU, kGroupWaves waves each
         void *t = nullptr, *g = nullptr;
-        const size_t gbytes = ((size_t)sc.n_slots * szk::kDualTablesPerGroup + 4) * sizeof(uint32_t);  // generations + [repeats, positions, next block]
+        const size_t gbytes = 64;  // [repeats, positions, next block] of a launch
         const size_t tbytes = (size_t)sc.n_slots * szk::kDualTablesPerGroup * szk::kDualTableBytes;
-        if (hipMalloc(&t, tbytes) == hipSuccess &&
-            hipMalloc(&g, gbytes) == hipSuccess &&
+        if (hipMalloc(&t, tbytes) == hipSuccess && hipMalloc(&g, gbytes) == hipSuccess &&
             hipMemsetAsync(t, 0, tbytes, stream) == hipSuccess &&
             hipMemsetAsync(g, 0, gbytes, stream) == hipSuccess) {
-            sc.tables = static_cast<uint32_t *>(t);
-            sc.gen = static_cast<uint32_t *>(g);
-            sc.select = sc.gen + (size_t)sc.n_slots * szk::kDualTablesPerGroup;
-            if (const char *gi = getenv("SZ_TEST_GEN_INIT")) {  // test hook: start near the 16-bit wrap
-                std::vector<uint32_t> init((size_t)sc.n_slots * szk::kDualTablesPerGroup, (uint32_t)strtoul(gi, nullptr, 0) & 0xffffu);
-                (void)hipMemcpy(g, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            }
+            sc.tables = static_cast<uint16_t *>(t);  // (every wave zeroes its table again before each block)
+            sc.select = static_cast<uint32_t *>(g);
         } else {
             (void)hipGetLastError();
             if (t) (void)hipFree(t);
@@ -94,8 +88,8 @@ void drop_dual_scratch(int dev, hipStream_t stream)
         return;
     if (it->second.tables)
         (void)hipFree(it->second.tables);
-    if (it->second.gen)
-        (void)hipFree(it->second.gen);
+    if (it->second.select)
+        (void)hipFree(it->second.select);
     g_dual.erase(it);
 }
 

@@ -241,45 +241,46 @@ __device__ __forceinline__ uint32_t sel6(uint32_t r0, uint32_t r1, uint32_t r2, 
 
 // The hash table of one block, in one of two homes:
 //  * LDS, 16384 x uint16, zeroed per block (32 KiB: four of them fit a CU, one per SIMD);
-//  * global memory (L2 / Infinity Cache), 16384 x uint32 entries tagged with a per-slot generation
-//    in the high half so that a new block needs no zeroing pass (an entry of another generation
-//    reads as 0 = empty).  Used by the extra waves of a SIMD in the multi-wave kernel, for which no
-//    LDS is left.
+//  * global memory (L2 / Infinity Cache), the same 16384 x uint16, zeroed per block by its wave (32 KiB
+//    of stores per 64 KiB block).  Used by the extra waves of a SIMD in the multi-wave kernel, for
+//    which no LDS is left.  (A first version had uint32 entries tagged with a generation instead of
+//    the zeroing pass; half the footprint is worth more: these tables live in L2, 4 MiB per XCD.)
 // NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
 // loads/stores with a vmcnt(0) wait after each.  The places that need "really re-read memory"
 // (other lanes of the same store may have won the bucket) use a compiler barrier.
 template <bool in_lds>
 struct HashTab {
     uint16_t *lds;
-    uint32_t *glob;
-    uint32_t tag;  // generation << 16
+    uint16_t *glob;
     uint32_t *bm;  // global home only: 16384-bit scratch bitmap in LDS (all zero between uses)
     static constexpr bool kInLds = in_lds;
 
+    // (relaxed wave-scope atomics = plain loads/stores that the compiler may neither forward nor
+    // merge: other lanes of this wave write the same entries)
     __device__ __forceinline__ uint32_t get(uint32_t h) const
     {
         if (in_lds)
             return __hip_atomic_load(lds + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        // (relaxed wave-scope atomics = plain global loads/stores that the compiler may neither
-        // forward nor merge: other lanes of this wave write the same entries)
-        const uint32_t e = __hip_atomic_load(glob + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        return (e & 0xffff0000u) == tag ? (e & 0xffffu) : 0u;
+        return __hip_atomic_load(glob + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     __device__ __forceinline__ void put(uint32_t h, uint32_t v) const
     {
         if (in_lds)
             __hip_atomic_store(lds + h, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         else
-            __hip_atomic_store(glob + h, tag | (v & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_store(glob + h, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     // (a2) table of T = 2^log2T entries, all empty
     __device__ __forceinline__ void clear(uint32_t log2T, uint32_t lane) const
     {
+        const uint32_t nvec = (1u << log2T) >> 3;  // 16-byte chunks
+        u32x4 z = {0, 0, 0, 0};
         if (in_lds) {
-            const uint32_t nvec = (1u << log2T) >> 3;  // 16-byte chunks
-            u32x4 z = {0, 0, 0, 0};
             for (uint32_t i = lane; i < nvec; i += 64)
                 reinterpret_cast<u32x4 *>(lds)[i] = z;
+        } else {
+            for (uint32_t i = lane; i < nvec; i += 64)
+                reinterpret_cast<u32x4 *>(glob)[i] = z;
         }
     }
 };
@@ -946,7 +947,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         out_len[b] = 0xffffffffu;  // (every lane, same address, same value: see the note at the dual kernel)
         return;
     }
-    const HashTab<true> tab{lds_tab, nullptr, 0u, nullptr};
+    const HashTab<true> tab{lds_tab, nullptr, nullptr};
     const uint32_t op = compress_one_block<64, false>(tab, src + (uint64_t)b * in_stride, n,
                                                dst + (uint64_t)b * dst_stride, flags, lane);
     out_len[b] = op;  // (a9) every lane, same address, same value
@@ -955,8 +956,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // Multi-wave ("dual") kernel: workgroups of kGroupWaves independent wavefronts, each compressing its
 // own blocks, four workgroups per CU, so that every SIMD hosts kGroupWaves waves and their
 // instruction latencies overlap (a lone wave issues ~1 instruction per 10 cycles).  Wave 0 keeps
-// its table in LDS; the others have generation-tagged tables in global memory (one slot each in
-// `scratch`).  Persistent grid: all waves pull block indices from one device-wide counter (zeroed
+// its table in LDS; the others have theirs in global memory (one 32 KiB slot each in `scratch`).  Persistent grid: all waves pull block indices from one device-wide counter (zeroed
 // by a tiny kernel ahead of the launch), so the faster (LDS-table) waves take more of them and
 // mixed workloads balance.  Measured on 64 KiB text blocks: 2 waves 42 GB/s, 3 waves 53, 4 waves 45,
 // 5 waves 42 (with three the SIMDs already have an instruction in flight 95 % of the time; more
@@ -971,8 +971,8 @@ static constexpr bool kDualLean = kGroupWaves >= 3;
 __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_eu(kGroupWaves, kGroupWaves))) void compress_blocks_dual_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
-    uint32_t *__restrict__ out_len, uint32_t flags, uint32_t *scratch_tables,
-    uint32_t *__restrict__ scratch_gen, uint32_t *__restrict__ select, uint32_t auto_mode)
+    uint32_t *__restrict__ out_len, uint32_t flags, uint16_t *scratch_tables,
+    uint32_t *__restrict__ select, uint32_t auto_mode)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
     __shared__ uint32_t dup_bm[(kGroupWaves - 1) * 512];  // one 16384-bit bitmap per global-table wave
@@ -984,10 +984,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
         for (uint32_t i = lane; i < 512; i += 64)
             dup_bm[(wave - 1) * 512u + i] = 0;
     const uint32_t my_slot = blockIdx.x * (kGroupWaves - 1) + (wave ? wave - 1 : 0);
-    uint32_t *my_glob = scratch_tables + (size_t)my_slot * kMaxTable;
-    uint32_t gen = 0;
-    if (wave >= 1)
-        gen = uni(scratch_gen[my_slot]);
+    uint16_t *my_glob = scratch_tables + (size_t)my_slot * kMaxTable;
     for (;;) {
         // One queue for the whole grid: faster waves take more blocks.  The counter's address goes
         // through VGPRs on purpose: experimental builds of this kernel that hung had `select` spilled
@@ -1011,17 +1008,11 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
         }
         uint32_t op;
         if (wave >= 1) {
-            gen = (gen + 1) & 0xffffu;
-            if (gen == 0) {  // generation wrapped: start over from an all-zero table
-                for (uint32_t i = lane; i < kMaxTable; i += 64)
-                    my_glob[i] = 0;
-                gen = 1;
-            }
-            const HashTab<false> tab{nullptr, my_glob, gen << 16, dup_bm + (wave - 1) * 512u};
+            const HashTab<false> tab{nullptr, my_glob, dup_bm + (wave - 1) * 512u};
             op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
         } else {
-            const HashTab<true> tab{lds_tab, nullptr, 0u, nullptr};
+            const HashTab<true> tab{lds_tab, nullptr, nullptr};
             op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
         }
@@ -1032,8 +1023,6 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
         // same source ran.  DESIGN.md section 7.
         out_len[b] = op;
     }
-    if (wave >= 1 && lane == 0)
-        scratch_gen[my_slot] = gen;
 }
 
 static constexpr uint32_t kSmallBlockMax = 8192;
@@ -1050,7 +1039,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks)
         return;
-    const HashTab<true> tab{dyn_tab, nullptr, 0u, nullptr};
+    const HashTab<true> tab{dyn_tab, nullptr, nullptr};
     const uint32_t op = compress_one_block<0, true>(tab, src + (uint64_t)b * block_bytes, block_bytes,
                                                     dst + (uint64_t)b * dst_stride, flags, lane);
     out_len[b] = op;  // (a9) every lane, same address, same value
@@ -1095,7 +1084,7 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
         grid = grid < dual->n_slots ? grid : dual->n_slots;
         hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(64 * kGroupWaves), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->tables,
-                           dual->gen, dual->select, dual->mode == kDualAuto ? 1u : 0u);
+                           dual->select, dual->mode == kDualAuto ? 1u : 0u);
     }
     return hipGetLastError();
 }

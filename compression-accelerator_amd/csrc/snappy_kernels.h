@@ -10,18 +10,17 @@ constexpr uint32_t kFlagBlockVarint = 1u;  // == SZ_FLAG_BLOCK_VARINT
 constexpr int32_t kStatusCorrupt = -74;    // == SZ_ECORRUPT
 constexpr int32_t kStatusNoSpace = -28;    // == SZ_ENOSPC
 
-// Workspace of the dual-wave kernel: n_slots generation-tagged tables (16384 x uint32 each) and one
-// generation counter per slot, both zero-initialised once; owned by one stream at a time.
+// Workspace of the multi-wave kernel: n_slots x (waves - 1) hash tables of 16384 x uint16 (zeroed by
+// their wave per block) and the launch state; owned by one stream at a time.
 enum DualMode : uint32_t { kDualAuto = 0, kDualAlways = 2 };
 struct DualScratch {
-    uint32_t *tables;
-    uint32_t *gen;
+    uint16_t *tables;
     uint32_t *select;     // [repeats, positions] of the compressibility sample + [next block] of the queue
     uint32_t n_slots;
     uint32_t min_blocks;  // launches with fewer blocks use the single kernel
     uint32_t mode;        // kDualAuto: pick single/dual per launch from a data sample
 };
-constexpr size_t kDualTableBytes = 16384 * 4;
+constexpr size_t kDualTableBytes = 16384 * 2;
 #ifndef SZ_GROUP_WAVES
 #define SZ_GROUP_WAVES 3
 #endif

@@ -27,7 +27,7 @@
  * negative SZ_E* on failure; no exceptions cross this boundary; no CPU fallback -- without a
  * usable GPU every compute entry point returns SZ_ENODEV / SZ_EHIP.
  * Device entry points are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
- * default stream) and never synchronise.  The compress entry points keep a 128 MiB workspace per
+ * default stream) and never synchronise.  The compress entry points keep a 64 MiB workspace per
  * (device, stream) for the three-waves-per-SIMD kernel; it is allocated by the first call on a stream
  * that is not being captured (a call made during graph capture before that simply uses the
  * one-wave kernel), so make one warm-up call before capturing a graph.  Which kernel runs is
@@ -36,7 +36,7 @@
  *
  * Environment (all optional, read per call): SZ_KERNEL=single|dual forces a compress kernel;
  * SZ_SERIAL_UNCOMPRESS=1 makes sz_uncompress skip the parallel fragment index (single-wavefront
- * decode of the whole stream); SZ_TEST_GEN_INIT, SZ_TEST_SEG_SHIFT are hooks of the test-suite.
+ * decode of the whole stream); SZ_TEST_SEG_SHIFT is a hook of the test-suite.
  */
 #ifndef SNAPPY_HIP_H
 #define SNAPPY_HIP_H
@@ -163,7 +163,7 @@ int sz_rocc_last_error(void);
 /* ---- misc ------------------------------------------------------------------------------- */
 /* Frees the calling thread's cached device workspace (used by the host-buffer API). */
 void sz_release_thread_resources(void);
-/* Frees the 128 MiB workspace the compress entry points keep for `stream` on the current device
+/* Frees the 64 MiB workspace the compress entry points keep for `stream` on the current device
  * (waits for the stream first).  Call it before destroying a stream that was used for compression
  * if the process creates many; the next compress call on the stream allocates a new one. */
 int sz_release_stream_resources(void *stream);

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(params=["auto", "single", "dual"], autouse=True)
 def kernel_mode(request, monkeypatch):
     """Every parity test runs through both compress kernels: `single` (one wave per SIMD, LDS
-    table) and `dual` (two waves per SIMD, the second with a generation-tagged table in global
+    table) and `dual` (three waves per SIMD, two of them with their tables in global
     memory), plus the default data-sampled choice.  The library reads SZ_KERNEL on every call."""
     if request.param == "auto":
         monkeypatch.delenv("SZ_KERNEL", raising=False)

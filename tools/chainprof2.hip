@@ -23,8 +23,7 @@ int main(int argc, char **argv)
     sc.n_slots = 1024; sc.min_blocks = 2; sc.mode = szk::kDualAlways;
     const size_t ntab = (size_t)sc.n_slots * szk::kDualTablesPerGroup;
     hipMalloc(&sc.tables, ntab * szk::kDualTableBytes); hipMemset(sc.tables, 0, ntab * szk::kDualTableBytes);
-    hipMalloc(&sc.gen, (ntab + 4) * 4); hipMemset(sc.gen, 0, (ntab + 4) * 4);
-    sc.select = sc.gen + ntab;
+    hipMalloc(&sc.select, 64); hipMemset(sc.select, 0, 64);
     const char *names[16] = {"window load+hash", "table lookup issue", "cand loads+compare", "walk+commit+verify", "emit", "long match",
                              "strided batch", "strided hit", "walk (per pass)", "commit+readback (per pass)", "lim", "cut windows", "hits/window", "advance/window", "", ""};
     for (int rep = 0; rep < 2; rep++) {
