@@ -26,14 +26,21 @@ namespace szk {
 
 // Diagnostic build only (tools/chainprof.hip compiles this file with -DSZ_PROF): cycle stamps per
 // phase, summed per block into g_prof.  Expands to nothing in the product build.
+// Analysis builds only (-DSZ_MARK): comments in the ISA at the phases of the fast dense path.
+#ifdef SZ_MARK
+#define MARK(name) asm volatile("; MARK " name)
+#else
+#define MARK(name) do { } while (0)
+#endif
+
 #ifdef SZ_PROF
-__device__ unsigned long long g_prof[64];  // [0,32): waves with the table in LDS, [32,64): in global memory
-#define PROF_DECL unsigned long long pt_ = 0, pacc_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned pcnt_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+__device__ unsigned long long g_prof[128];  // [0,64): waves with the table in LDS (32 sums, 32 counts), [64,128): in global memory
+#define PROF_DECL unsigned long long pt_ = 0, pacc_[32] = {}; unsigned pcnt_[32] = {};
 #define PROF_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt_) :: "memory"); } while (0)
 #define PROF_LAP(i) do { unsigned long long t2_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
 #define PROF_LAPV(i) do { unsigned long long t2_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
 #define PROF_ADD(i, v) do { pacc_[i] += (unsigned long long)(v); pcnt_[i]++; } while (0)
-#define PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) { const int b_ = Tab::kInLds ? 0 : 32; for (int i_ = 0; i_ < 16; i_++) { atomicAdd(&g_prof[b_ + i_], pacc_[i_]); atomicAdd(&g_prof[b_ + 16 + i_], (unsigned long long)pcnt_[i_]); } } } while (0)
+#define PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) { const int b_ = Tab::kInLds ? 0 : 64; for (int i_ = 0; i_ < 32; i_++) { atomicAdd(&g_prof[b_ + i_], pacc_[i_]); atomicAdd(&g_prof[b_ + 32 + i_], (unsigned long long)pcnt_[i_]); } } } while (0)
 #else
 #define PROF_DECL
 #define PROF_START() do { } while (0)
@@ -46,6 +53,7 @@ __device__ unsigned long long g_prof[64];  // [0,32): waves with the table in LD
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxTable = 16384u;
 static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
+static constexpr uint32_t kFastMargin = 128u;  // the fast dense path stays this far from the last probe position
 
 // Probe schedule of the scan loop after a (re)start: off[k] = distance of the k-th probe from the
 // first one.  skip_0 = 32, off_{k+1} = off_k + (skip_k >> 5), skip_{k+1} = skip_k + (skip_k >> 5).
@@ -208,6 +216,15 @@ __device__ __forceinline__ uint32_t match_length(const uint8_t *__restrict__ in,
     }
 }
 
+// Wave-uniform by construction, said so to the compiler (free where it already knows: a readfirstlane
+// of a scalar value folds away; where it does not, this is what brings the value back from vector
+// registers into scalar ones)
+__device__ __forceinline__ uint64_t uni64(uint64_t v)
+{
+    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+__device__ __forceinline__ bool unib(bool v) { return uni(v ? 1u : 0u) != 0; }
+
 // select among six registers by a wave-uniform index (kept as scalars on purpose: an array here
 // is turned into a scratch lookup by the compiler)
 __device__ __forceinline__ uint32_t sel6(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t r4,
@@ -291,13 +308,13 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
                                                        uint32_t lane)
 {
-    uint32_t op = 0;
-    if (flags & kFlagBlockVarint) {  // (a8) varint32(n), n <= 65536 -> at most 3 bytes
-        const uint32_t nb = n < 128 ? 1 : (n < 16384 ? 2 : 3);
-        if (lane < nb)
-            out[lane] = (uint8_t)(((n >> (7 * lane)) & 0x7f) | (lane + 1 < nb ? 0x80 : 0));
-        op = nb;
-    }
+    // (a8) varint32(n), n <= 65536 -> at most 3 bytes.  (`op` is a select of wave-uniform values, not a
+    // value merged behind the per-lane `if`: the compiler keeps the whole parse state in scalar
+    // registers only while it can prove it uniform -- `opt -passes='print<uniformity>'`.)
+    const uint32_t nb = (flags & kFlagBlockVarint) ? (n < 128 ? 1u : (n < 16384 ? 2u : 3u)) : 0u;
+    if (lane < nb)
+        out[lane] = (uint8_t)(((n >> (7 * lane)) & 0x7f) | (lane + 1 < nb ? 0x80 : 0));
+    uint32_t op = nb;
     if (n == 0)
         return op;
 
@@ -430,7 +447,20 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             if (posN < ip_limit && lane >= firstN)
                 candN = tab.get(hN);  // table as of the start of the window
         };
-        prep(1, false);
+        // (requested where the next window's start becomes known, run at the top of the general dense
+        // window: the fast path below has its own, tile-based head)
+        uint32_t prepW = 1;
+        bool prepC = false, prepped = false;
+        auto want_prep = [&](uint32_t Wn, bool chainN) {
+            prepW = Wn;
+            prepC = chainN;
+            prepped = false;
+        };
+
+        // fast dense path: constants per lane, and "the general code takes the next window"
+        const uint32_t lane4 = (lane >> 2) << 2, lane3 = lane & 3u;
+        const uint32_t run32 = lane <= 32 ? 32u : 0xffffffffu;
+        bool hold_fast = false;
 
         uint32_t P = 1;          // next position to probe
         bool chain = false;      // P ends a copy: insert P-1, probe P
@@ -443,6 +473,15 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         // -- memory that does not hold what this wave wrote -- into an error marker instead of a hang)
         uint32_t trips = 0;
         for (;;) {
+            // The parse state is wave-uniform by construction; say so at every trip.  Inside a trip the
+            // compiler keeps it in scalar registers only while it can PROVE it uniform, and the general
+            // window code below has joins behind per-lane branches where it cannot (checked with
+            // `opt -passes='print<uniformity>'`): without this the whole state, this trip's and every later
+            // one's, lives in vector registers and the mask arithmetic runs as 64-bit vector instructions.
+            P = uni(P); chain = unib(chain); sc = uni(sc); scan_base = uni(scan_base); next_emit = uni(next_emit);
+            op = uni(op); kcur = uni(kcur); trips = uni(trips); poisoned = unib(poisoned); hold_fast = unib(hold_fast);
+            prepW = uni(prepW); prepC = unib(prepC); prepped = unib(prepped); first_scan = unib(first_scan);
+            big_len = uni(big_len);
             if (poisoned || ++trips > 2u * kMaxBlock) {
                 poisoned = true;
                 break;
@@ -451,10 +490,357 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             if (flags & 0x200u)  // timing ablation: no match finding at all (one literal)
                 break;
 #endif
+
+#ifndef SZ_NO_FAST
+            if (chain && !hold_fast && P + kFastMargin <= ip_limit) {
+                // =================================================== FAST DENSE PATH (fixed tiles)
+                // Compressible data spends its time here.  The block is cut into fixed tiles of 64
+                // positions (lane l of tile t = position 64 t + l), so the bytes of a tile come out of
+                // the register buffers with constant shuffles, and a tile keeps its per-lane results
+                // (hash, candidate, local match length) while the parse visits it once or several
+                // times: a VISIT walks the lanes [e, lim) from the state (chain, sc) and commits their
+                // table inserts.  Two inserted lanes that share a bucket end the visit before the second
+                // one (lim = cut); the same tile is then visited again from there, and only the lanes
+                // whose bucket was written in between get a new candidate -- nothing else of the tile
+                // is recomputed.  The elements of a tile are written once, when the parse leaves it
+                // (masks of all its visits accumulated).  States this path does not take (a scan that
+                // may reach probe 32, the last ~128 bytes of the block) go back to the general code
+                // above/below with (P, chain, sc, next_emit) as they stand.
+                // tests/tile_model.py states the same algebra in plain integers (checked on the CPU).
+                uint32_t t = P >> 6, e = P & 63u;
+                bool c_in = true;
+                uint32_t sc_in = 0;
+                first_scan = false;
+                u32x4 ta, ta2;                 // bytes [pos, pos + 32) of the lane's position
+                uint32_t th, tcand, tml = 0;   // hash, candidate as of the last lookup, match length 4..32
+                uint64_t Hraw = 0, El = 0;     // lanes whose candidate matches / whose match reaches 32 bytes
+                auto tile_head = [&](uint32_t tt, uint32_t ee, bool cc, bool pm1_done) {
+                    const uint32_t k = tt >> 1;  // buffer k = bytes [128 k, 128 k + 256) holds the tile + 32
+                    if (k != kcur) {
+                        wcur = k == kcur + 1 ? wnxt : load_buf(k);
+                        wnxt = load_buf(k + 1);
+                        kcur = k;
+                    }
+                    const uint32_t i0 = ((tt & 1u) << 6) + lane4;
+                    uint32_t d[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++)
+                        d[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i0 + 4 * q), (int)wcur);
+                    ta.x = __builtin_amdgcn_alignbyte(d[1], d[0], lane3);
+                    ta.y = __builtin_amdgcn_alignbyte(d[2], d[1], lane3);
+                    ta.z = __builtin_amdgcn_alignbyte(d[3], d[2], lane3);
+                    ta.w = __builtin_amdgcn_alignbyte(d[4], d[3], lane3);
+                    ta2.x = __builtin_amdgcn_alignbyte(d[5], d[4], lane3);
+                    ta2.y = __builtin_amdgcn_alignbyte(d[6], d[5], lane3);
+                    ta2.z = __builtin_amdgcn_alignbyte(d[7], d[6], lane3);
+                    ta2.w = __builtin_amdgcn_alignbyte(d[8], d[7], lane3);
+                    th = (ta.x * kHashMul) >> shift;
+                    if (cc && !pm1_done) {  // the reference inserts P-1 before it looks P up
+                        if (ee >= 1) {
+                            if (lane == ee - 1)
+                                tab.put(th, (tt << 6) + lane);
+                        } else if (lane == 0) {
+                            const uint32_t pm1 = (tt << 6) - 1;
+                            tab.put((ld32(in + pm1) * kHashMul) >> shift, pm1);
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                    tcand = tab.get(th);  // all 64 positions: table as it stands
+                };
+                // candidate bytes -> hit mask and local match lengths, for the lanes in `sel`
+                auto tile_compare = [&](uint64_t sel) {
+                    const bool on = __builtin_amdgcn_inverse_ballot_w64(sel);
+                    u32x4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+                    if (on) {
+                        c = ld128(in + tcand);  // tcand < pos, pos + 32 <= n here
+                        c2 = ld128(in + tcand + 16);
+                    }
+                    const uint32_t ml = matchlen32(ta, ta2, c, c2);
+                    const uint64_t hit = __ballot(on && c.x == ta.x);
+                    Hraw = (Hraw & ~sel) | hit;
+                    El = (El & ~sel) | (__ballot(ml == 32) & hit);
+                    tml = on ? ml : tml;
+                };
+                // elements closed inside the accumulated visits of the tile
+                uint64_t Vacc = 0, Hpacc = 0;
+                bool acc_open = false;
+                uint32_t acc_emit = next_emit;
+                auto flush_tile = [&](uint32_t tt, uint32_t long_lane) {
+                    if (Hpacc == 0)
+                        return;
+                    const uint32_t jfirst = ctz64(Hpacc);
+                    const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hpacc);
+                    uint64_t Lit = Vacc & ~Hpacc & below63(jlast);
+                    if (acc_open) {  // a literal was open when the accumulation began: it ends at the first hit
+                        emit_lit(acc_emit, (tt << 6) + jfirst - acc_emit);
+                        Lit &= ~below63(jfirst);
+                    }
+                    const uint64_t RS = Lit & ~(Lit << 1);
+                    const uint64_t HC = long_lane < 64 ? Hpacc & ~(1ull << long_lane) : Hpacc;
+                    const bool is_lit = __builtin_amdgcn_inverse_ballot_w64(Lit);
+                    const bool run_start = __builtin_amdgcn_inverse_ballot_w64(RS);
+                    const bool is_hit = __builtin_amdgcn_inverse_ballot_w64(HC);
+                    const uint32_t runlen = (uint32_t)__builtin_ctzll((Hpacc >> lane) | (1ull << 63));
+                    const uint32_t abyte = ta.x & 0xffu;
+                    const uint32_t off = (tt << 6) + lane - tcand;
+                    const bool short_form = tml < 12 && off < 2048;
+                    uint32_t cnt = 0, word = 0;
+                    if (is_lit) {
+                        cnt = run_start ? 2 : 1;
+                        word = run_start ? (((runlen - 1) << 2) | (abyte << 8)) : abyte;
+                    } else if (is_hit) {
+                        cnt = short_form ? 2 : 3;
+                        word = short_form ? (1u | ((tml - 4) << 2) | ((off >> 8) << 5) | ((off & 0xffu) << 8))
+                                          : (2u | ((tml - 1) << 2) | (off << 8));
+                    }
+                    const uint32_t incl = wave_inclusive_sum(cnt);
+                    uint8_t *o = out + (op + (incl - cnt));
+                    if (cnt >= 1) o[0] = (uint8_t)word;
+                    if (cnt >= 2) o[1] = (uint8_t)(word >> 8);
+                    if (cnt >= 3) o[2] = (uint8_t)(word >> 16);
+                    op += lane_get(incl, 63);
+                };
+
+                PROF_LAP(14);
+                tile_head(t, e, true, false);
+                PROF_LAP(20);
+                tile_compare(~0ull);
+                PROF_LAPV(22);
+                for (;;) {
+                    if (++trips > 2u * kMaxBlock) {
+                        poisoned = true;
+                        break;
+                    }
+                    MARK("visit_top");
+#ifdef SZ_UNI_PROBE
+                    t = uni(t); e = uni(e); c_in = unib(c_in); sc_in = uni(sc_in); Hraw = uni64(Hraw); El = uni64(El);
+                    Vacc = uni64(Vacc); Hpacc = uni64(Hpacc); acc_open = unib(acc_open); acc_emit = uni(acc_emit);
+                    next_emit = uni(next_emit); op = uni(op); kcur = uni(kcur); trips = uni(trips);
+#endif
+                    const uint32_t pos = (t << 6) + lane;
+                    const uint64_t Hm = Hraw & ~below63(e);
+                    // ---- where the parse goes from each lane: to the next hit at or after it, then past
+                    // that hit's match (64 = out of the tile; a match that reaches 32 bytes ends the visit)
+                    const uint64_t tl = Hm >> lane;
+                    uint32_t dlo, dhi;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(dlo) : "v"((uint32_t)tl));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(dhi) : "v"((uint32_t)(tl >> 32)));
+                    dhi |= 32u;
+                    uint32_t dist = dlo < dhi ? dlo : dhi;  // 0xffffffff: no hit from here on
+                    dist = dist < 64u ? dist : 64u;
+                    const uint32_t nh = lane + dist;
+                    const uint32_t mlw = tml == 32 ? 64u : tml;
+                    const uint32_t m_nh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nh << 2), (int)mlw);
+                    uint32_t vJ = nh + m_nh;
+                    vJ = vJ > lane ? vJ : lane + 1;  // (always so for a hit: ml >= 4; keeps the walk finite whatever memory holds)
+                    vJ = vJ < 64u ? vJ : 64u;
+                    // ---- states left to the general code: a scan could reach probe 32 (32 hit-free lanes
+                    // in a row, or the misses carried in plus those before the first hit)
+                    const uint64_t far = __ballot(dist >= run32) & ~below63(e);
+                    const uint32_t lead = (Hm ? ctz64(Hm) : 64u) - e;
+                    if (far != 0 || (!c_in && sc_in + lead > 31)) {
+                        flush_tile(t, 64);
+                        P = (t << 6) + e;
+                        chain = c_in;
+                        sc = sc_in;
+                        hold_fast = true;
+                        break;
+                    }
+                    PROF_LAP(15);
+                    MARK("walk_loop");
+                    // ---- the serial part: one v_readlane per element
+                    uint64_t S = 0;
+                    uint32_t jj = e;
+                    do {
+                        S |= 1ull << jj;
+                        jj = lane_get(vJ, jj);
+                    } while (jj < 64);
+                    PROF_LAP(16);
+                    MARK("exit_commit");
+                    // ---- exit state for the limit `lim`, commit, check; a shared bucket repeats it once
+                    uint32_t lim = 64;
+                    uint64_t V, Hp, Ins, C;
+                    uint32_t P2, sc2, long_lane, emit2;
+                    bool chain2, pm1_done, committed = false, bad_cut = false;
+                    for (;;) {
+                        const uint64_t bl = lanes_below(lim);
+                        const uint64_t Hm_t = Hm & bl, Sx = S & bl;
+                        const uint32_t s_l = 63u - (uint32_t)__builtin_clzll(Sx);  // (lane e is in Sx)
+                        const uint64_t Hx = Hm_t >> s_l;
+                        Hp = Hm_t & ~(Hm_t - Sx);  // first hit of every segment [start, next start)
+                        long_lane = 64;
+                        emit2 = next_emit;
+                        pm1_done = false;
+                        if (Hx == 0) {  // the literal / scan is still open at lim
+                            V = (((Hp << 1) | (lim < 64 ? 1ull << lim : 0ull)) - Sx) & bl;
+                            chain2 = false;
+                            P2 = (t << 6) + lim;
+                            if (Sx == (1ull << e) && !c_in) {
+                                sc2 = sc_in + lim - e;
+                            } else {
+                                emit2 = (t << 6) + s_l;
+                                sc2 = lim - s_l - 1;
+                            }
+                        } else {
+                            V = (Hp << 1) - Sx;
+                            const uint32_t jx = s_l + ctz64(Hx);
+                            const uint32_t mj = lane_get(tml, jx);
+                            chain2 = true;
+                            sc2 = 0;
+                            P2 = (t << 6) + jx + mj;
+                            emit2 = P2;
+                            if (mj == 32)
+                                long_lane = jx;
+                            else if (lim == 64 && jx + mj == 64)
+                                pm1_done = true;  // the copy ends with the tile: its last byte is the next P-1
+                        }
+                        Ins = (Sx & ~(1ull << e)) >> 1;  // the lane before each chain probe
+                        if (pm1_done)
+                            Ins |= 1ull << 63;
+                        C = V | Ins;
+                        // (every exit of this loop is taken by the whole wave, right after wave-uniform
+                        // code: a `break` behind a per-lane `if` makes the compiler treat the masks and the
+                        // state computed here as per-lane values and move them into vector registers)
+                        if (lim < 64)
+                            break;  // lanes below a cut share no bucket: committed below
+                        const bool inC = __builtin_amdgcn_inverse_ballot_w64(C);
+                        uint64_t L;
+                        if constexpr (Tab::kInLds) {
+                            uint32_t w = pos & 0xffffu;
+                            if (inC) {
+                                tab.put(th, pos);
+                                asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
+                                w = tab.get(th);
+                            }
+                            L = __ballot(inC && w != (pos & 0xffffu));
+                            committed = L == 0;
+                        } else {
+                            const uint32_t bit = 1u << (th & 31u);
+                            uint32_t old = 0;
+                            if (inC)
+                                old = __hip_atomic_fetch_or(tab.bm + (th >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            if (inC)
+                                __hip_atomic_store(tab.bm + (th >> 5), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            L = __ballot(inC && (old & bit));
+                        }
+                        if (L == 0)
+                            break;
+                        if constexpr (Tab::kInLds) {
+                            asm volatile("" ::: "memory");
+                            if (inC)
+                                tab.put(th, tcand);  // roll back (lanes of one bucket hold the same old entry)
+                        }
+                        uint32_t cut = 64;
+                        while (L) {
+                            const uint32_t hv = lane_get(th, ctz64(L));
+                            const uint64_t G = __ballot(inC && th == hv);
+                            L &= ~G;
+                            const uint64_t G2 = G & (G - 1);
+                            const uint32_t second = ctz64(G2);
+                            cut = second < cut ? second : cut;
+                        }
+                        // (cut <= e or no cut at all cannot happen: a lost write that no shared bucket
+                        // explains.  The block is poisoned below instead of looping on it.)
+                        bad_cut = cut <= e || cut >= 64;
+                        lim = bad_cut ? e + 1 : cut;
+                    }
+                    if (!committed) {  // the final set of inserts (below a cut, or a global-memory table)
+                        if (__builtin_amdgcn_inverse_ballot_w64(C))
+                            tab.put(th, pos);
+                    }
+                    poisoned = poisoned || bad_cut;
+                    if (poisoned)
+                        break;
+                    PROF_LAP(17);
+                    MARK("after_commit");
+                    next_emit = emit2;
+                    Vacc |= V;
+                    Hpacc |= Hp;
+                    if (long_lane < 64) {  // the last hit's match runs past its 32 local bytes: finish it
+                        flush_tile(t, long_lane);
+                        const uint32_t ip = (t << 6) + long_lane, cnd = lane_get(tcand, long_lane);
+                        const uint32_t m = match_length(in, cnd, ip, n, lane, 32);
+                        op = emit_copy(out, op, ip - cnd, m, lane);
+                        P2 = ip + m;
+                        next_emit = P2;
+                        Vacc = 0;
+                        Hpacc = 0;
+                        acc_open = false;
+                        acc_emit = P2;
+                    }
+                    const uint32_t t2 = P2 >> 6, e2 = P2 & 63u;
+                    PROF_LAPV(18);
+                    MARK("next_tile");
+                    if (t2 != t) {
+                        const bool go_on = P2 + kFastMargin <= ip_limit;
+                        const u32x4 oa = ta;  // the tile being left: its elements go out under the new tile's loads
+                        const uint32_t ocand = tcand, oml = tml;
+                        MARK("head");
+                        if (go_on)
+                            tile_head(t2, e2, chain2, pm1_done);
+                        PROF_LAP(20);
+                        MARK("flush");
+                        {
+                            const u32x4 na = ta;
+                            const uint32_t ncand = tcand;
+                            ta = oa;
+                            tcand = ocand;
+                            flush_tile(t, 64);
+                            ta = na;
+                            tcand = ncand;
+                            (void)oml;
+                        }
+                        Vacc = 0;
+                        Hpacc = 0;
+                        acc_open = !chain2;
+                        acc_emit = next_emit;
+                        if (!go_on) {
+                            P = P2;
+                            chain = chain2;
+                            sc = sc2;
+                            break;
+                        }
+                        t = t2;
+                        PROF_LAP(21);
+                        MARK("compare");
+                        tile_compare(~0ull);
+                        MARK("compare_end");
+                        PROF_LAPV(22);
+                    } else {
+                        // the same tile again (after a cut or a long match): insert P-1, then give the lanes
+                        // whose bucket was written since their lookup the new candidate
+                        if (chain2 && lane == e2 - 1)
+                            tab.put(th, pos);
+                        asm volatile("" ::: "memory");
+                        const uint32_t cnow = tab.get(th);
+                        const uint64_t stale = __ballot(cnow != tcand) & ~below63(e2);
+                        if (stale) {
+                            tcand = __builtin_amdgcn_inverse_ballot_w64(stale) ? cnow : tcand;
+                            tile_compare(stale);
+                        }
+                        PROF_LAPV(23);
+                    }
+                    e = e2;
+                    c_in = chain2;
+                    sc_in = sc2;
+                    PROF_LAP(19);
+                    MARK("visit_end");
+                }
+                if (!chain)
+                    scan_base = P - sc;
+                want_prep(P - (chain ? 1u : 0u), chain);
+                continue;
+            }
+#endif
             if (chain || sc <= 31) {
                 // =================================================== dense window
                 if (P >= ip_limit)
                     break;  // remainder
+                hold_fast = false;
+                if (!prepped) {
+                    prep(prepW, prepC);
+                    prepped = true;
+                }
                 const uint32_t first = chain ? 1u : 0u;
                 const uint32_t W0 = P - first;
                 const uint32_t pos = W0 + lane;
@@ -682,9 +1068,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         next_emit = P;
                     else if (lit_lane < 64)
                         next_emit = W0 + lit_lane;
-                    if (chain || sc <= 31) {
-                        prep(P - (chain ? 1u : 0u), chain);
-                    }
+                    if (chain || sc <= 31)
+                        want_prep(P - (chain ? 1u : 0u), chain);
                 }
                 first_scan = first_scan && !Hp && (scan_base == 1);
 
@@ -736,7 +1121,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     chain = true;
                     sc = 0;
                     next_emit = P;
-                    prep(P - 1, true);
+                    want_prep(P - 1, true);
                 }
                 PROF_LAP(5);
                 continue;
@@ -832,7 +1217,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             sc = 0;
             next_emit = P;
             first_scan = false;
-            prep(P - 1, true);
+            want_prep(P - 1, true);
             PROF_LAP(7);
         }
         PROF_FLUSH();

@@ -24,27 +24,30 @@ int main(int argc, char **argv)
     const size_t ntab = (size_t)sc.n_slots * szk::kDualTablesPerGroup;
     hipMalloc(&sc.tables, ntab * szk::kDualTableBytes); hipMemset(sc.tables, 0, ntab * szk::kDualTableBytes);
     hipMalloc(&sc.select, 64); hipMemset(sc.select, 0, 64);
-    const char *names[16] = {"window load+hash", "table lookup issue", "cand loads+compare", "walk+commit+verify", "emit", "long match",
-                             "strided batch", "strided hit", "walk (per pass)", "commit+readback (per pass)", "lim", "cut windows", "hits/window", "advance/window", "", ""};
+    const char *names[32] = {"window load+hash", "table lookup issue", "cand loads+compare", "walk+commit+verify", "emit", "long match",
+                             "strided batch", "strided hit", "walk (per pass)", "commit+readback (per pass)", "lim", "cut windows", "hits/window", "advance/window",
+                             "F: enter (since last lap)", "F: visit top + walk prep", "F: walk loop", "F: exit + commit", "F: next/long (vm drained)", "F: visit end",
+                             "F: tile head", "F: flush", "F: compare (vm drained)", "F: same-tile validate", "", "", "", "", "", "", "", ""};
     for (int rep = 0; rep < 2; rep++) {
-        unsigned long long z[64] = {0};
+        unsigned long long z[128] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(szk::g_prof), z, sizeof z);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0);
         szk::launch_compress_blocks(d_in, 65536, nullptr, nb, d_out, 76544, d_len, 1, &sc, 0);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        unsigned long long p[64];
+        unsigned long long p[128];
         hipMemcpyFromSymbol(p, HIP_SYMBOL(szk::g_prof), sizeof p);
         if (rep == 1) {
             printf("nb=%u kernel %.3f ms  %.1f GB/s\n", nb, ms, nb * 65536.0 / ms / 1e6);
             for (int t = 0; t < 2; t++) {
-                const unsigned long long *q = p + 32 * t;
+                const unsigned long long *q = p + 64 * t;
                 unsigned long long tot = 0;
                 for (int i = 0; i < 10; i++) tot += q[i];
-                printf("--- %s waves: %llu windows, %.0f ticks(10ns) per window total\n", t ? "GLOBAL-table" : "LDS-table", q[16 + 3], (double)tot / (q[16 + 3] ? q[16 + 3] : 1));
-                for (int i = 0; i < 16; i++)
-                    if (q[16 + i])
-                        printf("  %-22s total %12llu  count %9llu  avg %8.2f  (%4.1f%%)\n", names[i], q[i], q[16 + i], (double)q[i] / q[16 + i], i < 10 ? 100.0 * q[i] / tot : 0.0);
+                for (int i = 14; i < 24; i++) tot += q[i];
+                printf("--- %s waves: %llu windows + %llu tiles (%llu visits), %.0f ticks in all\n", t ? "GLOBAL-table" : "LDS-table", q[32 + 3], q[32 + 21], q[32 + 15], (double)tot);
+                for (int i = 0; i < 32; i++)
+                    if (q[32 + i])
+                        printf("  %-28s total %12llu  count %9llu  avg %8.2f  (%4.1f%%)\n", names[i], q[i], q[32 + i], (double)q[i] / q[32 + i], (i < 10 || (i >= 14 && i < 24)) ? 100.0 * q[i] / tot : 0.0);
             }
         }
     }
