@@ -26,6 +26,12 @@ namespace szk {
 
 // Diagnostic build only (tools/chainprof.hip compiles this file with -DSZ_PROF): cycle stamps per
 // phase, summed per block into g_prof.  Expands to nothing in the product build.
+// Placed behind a per-lane `if` that would otherwise be the last statement of a wave-uniform branch
+// arm: keeps the point where the lanes meet again a block of its own.  Without it that point is merged
+// with the point where the wave-uniform arms meet, and the compiler then has to assume that every value
+// merged there differs between lanes (vector registers, 64-bit vector arithmetic for the masks).
+#define UNIFORM_JOIN() asm volatile("")
+
 // Analysis builds only (-DSZ_MARK): comments in the ISA at the phases of the fast dense path.
 #ifdef SZ_MARK
 #define MARK(name) asm volatile("; MARK " name)
@@ -53,6 +59,9 @@ __device__ unsigned long long g_prof[128];  // [0,64): waves with the table in L
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxTable = 16384u;
 static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
+#ifndef SZ_SPEC_MODE
+#define SZ_SPEC_MODE 0  // head of the next tile issued ahead of the walk: 0 never (measured best), 1 waves with the table in LDS, 2 all
+#endif
 static constexpr uint32_t kFastMargin = 128u;  // the fast dense path stays this far from the last probe position
 
 // Probe schedule of the scan loop after a (re)start: off[k] = distance of the k-th probe from the
@@ -151,11 +160,25 @@ __device__ __forceinline__ uint32_t emit_copy(uint8_t *__restrict__ out, uint32_
     if (len > 64) {
         const uint32_t k64 = (len - 4) >> 6;  // number of leading 64-byte elements
         rest = len - (k64 << 6);              // 4..67
+        // the 3-byte element [fe lo hi] repeated k64 times: written as (unaligned) dwords of the
+        // period-3 byte pattern -- dword j starts at pattern phase j mod 3 -- plus up to 3 tail bytes
         const uint32_t w64 = 0xfeu | (lo << 8) | (hi << 16);  // 2 | (63<<2)
-        for (uint32_t j = lane; j < 3 * k64; j += 64)
-            o[j] = (uint8_t)(w64 >> (8 * (j % 3)));
-        o += 3 * k64;
-        bytes = 3 * k64;
+        const uint32_t total = 3 * k64, nd = total >> 2;
+        const uint32_t p0 = w64 | (w64 << 24);                          // fe lo hi fe
+        const uint32_t p1 = (w64 >> 8) | (w64 << 16);                   // lo hi fe lo
+        const uint32_t q2 = (hi) | (0xfeu << 8) | (lo << 16) | (hi << 24);  // hi fe lo hi
+        for (uint32_t j = lane; j < nd; j += 64) {
+            const uint32_t ph = j % 3u;
+            const uint32_t v = ph == 0 ? p0 : (ph == 1 ? p1 : q2);
+            __builtin_memcpy(o + 4 * (size_t)j, &v, 4);
+        }
+        const uint32_t tail = total & 3u;
+        if (lane < tail) {
+            const uint32_t jb = (nd << 2) + lane;
+            o[jb] = (uint8_t)(w64 >> (8 * (jb % 3u)));
+        }
+        o += total;
+        bytes = total;
         if (rest > 64) {
             const uint32_t w60 = 0xeeu | (lo << 8) | (hi << 16);  // 2 | (59<<2)
             if (lane < 3)
@@ -190,16 +213,42 @@ __device__ __forceinline__ uint32_t match_length(const uint8_t *__restrict__ in,
             return m + ctz64(ne);
         m += 64;
     }
-    while (ip + m + 1024 <= n) {  // long match: 16 B per lane, 1 KiB per step
-        const u32x4 a = ld128(in + cand + m + 16 * lane);
-        const u32x4 b = ld128(in + ip + m + 16 * lane);
+    // long match: 16 B per lane and KiB; 4 KiB of both strings in flight per step while that much is left
+    auto eq16 = [&](const u32x4 &a, const u32x4 &b) -> uint32_t {  // equal leading bytes of two 16-byte strings
         const uint32_t d0 = a.x ^ b.x, d1 = a.y ^ b.y, d2 = a.z ^ b.z, d3 = a.w ^ b.w;
         uint32_t eqb = 16;
         if (d3) eqb = 12 + (__builtin_ctz(d3) >> 3);
         if (d2) eqb = 8 + (__builtin_ctz(d2) >> 3);
         if (d1) eqb = 4 + (__builtin_ctz(d1) >> 3);
         if (d0) eqb = (__builtin_ctz(d0) >> 3);
-        const uint64_t ne = __ballot(eqb < 16);
+        return eqb;
+    };
+    while (ip + m + 4096 <= n) {
+        u32x4 a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            a[k] = ld128(in + cand + m + 1024 * k + 16 * lane);
+            b[k] = ld128(in + ip + m + 1024 * k + 16 * lane);
+        }
+        uint32_t res = 0xffffffffu;  // length at the first difference, if there is one in these 4 KiB
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const uint32_t eqb = eq16(a[k], b[k]);
+            const uint64_t ne = ballot64(eqb < 16);
+            if (ne) {
+                const uint32_t f = ctz64(ne);
+                res = m + 1024 * k + 16 * f + lane_get(eqb, f);
+            }
+        }
+        if (res != 0xffffffffu)
+            return res;
+        m += 4096;
+    }
+    while (ip + m + 1024 <= n) {
+        const u32x4 a = ld128(in + cand + m + 16 * lane);
+        const u32x4 b = ld128(in + ip + m + 16 * lane);
+        const uint32_t eqb = eq16(a, b);
+        const uint64_t ne = ballot64(eqb < 16);
         if (ne) {
             const uint32_t f = ctz64(ne);
             return m + 16 * f + lane_get(eqb, f);
@@ -342,12 +391,26 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         // shuffles (ds_bpermute: LDS crossbar, no memory access) and v_alignbyte.
         const uint32_t last16 = n - 16;  // n >= 15 here; (n == 15: no position is probed at all)
         u32x4 a = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
-        uint32_t wcur = 0, wnxt = 0, kcur = 0;  // buffers kcur and kcur + 1
-        auto load_buf = [&](uint32_t k) -> uint32_t {
+        uint32_t wcur = 0, wnxt = 0, wnxt_sh = 0, kcur = 0;  // buffers kcur and kcur + 1
+        // (the prefetched buffer stays as loaded until it becomes the current one: the shift that puts
+        // the last bytes of a block where they belong is applied then, not behind the load -- a use
+        // right behind the load would make the wave wait for it)
+        auto fetch_buf = [&](uint32_t k, uint32_t &sh8) -> uint32_t {
             const uint32_t o = (k << 7) + 4u * lane;
             const uint32_t oc = o < n - 4u ? o : n - 4u;  // stay inside the block ...
             const uint32_t sh = o - oc < 3u ? o - oc : 3u;
-            return ld32(in + oc) >> (8u * sh);             // ... and keep its last bytes where they belong
+            sh8 = 8u * sh;                                 // ... and keep its last bytes where they belong
+            return ld32(in + oc);
+        };
+        auto load_buf = [&](uint32_t k) -> uint32_t {
+            uint32_t sh8;
+            const uint32_t v = fetch_buf(k, sh8);
+            return v >> sh8;
+        };
+        auto advance_bufs = [&](uint32_t k) {  // buffers k and k + 1 become current / prefetched
+            wcur = k == kcur + 1 ? wnxt >> wnxt_sh : load_buf(k);
+            wnxt = fetch_buf(k + 1, wnxt_sh);
+            kcur = k;
         };
         auto cut_window = [&](uint32_t W) {  // a, a2 := bytes [W+lane, W+lane+32); needs kcur == W >> 7
             const uint32_t s0 = (W & 127u) + lane;  // <= 190: dwords s0/4 .. s0/4+8 <= 55 of the buffer
@@ -367,16 +430,13 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         };
         auto load_window = [&](uint32_t W) {
             const uint32_t k = W >> 7;
-            if (k != kcur) {
-                wcur = k == kcur + 1 ? wnxt : load_buf(k);
-                wnxt = load_buf(k + 1);
-                kcur = k;
-            }
+            if (k != kcur)
+                advance_bufs(k);
             cut_window(W);
         };
         if (n >= 16) {
             wcur = load_buf(0);
-            wnxt = load_buf(1);
+            wnxt = fetch_buf(1, wnxt_sh);
         }
 
         // Whole-block register prefetch (blocks >= 16 KiB), issued right behind the probe loads above
@@ -446,6 +506,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             candN = 0;
             if (posN < ip_limit && lane >= firstN)
                 candN = tab.get(hN);  // table as of the start of the window
+            UNIFORM_JOIN();
         };
         // (requested where the next window's start becomes known, run at the top of the general dense
         // window: the fast path below has its own, tile-based head)
@@ -501,330 +562,362 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 // times: a VISIT walks the lanes [e, lim) from the state (chain, sc) and commits their
                 // table inserts.  Two inserted lanes that share a bucket end the visit before the second
                 // one (lim = cut); the same tile is then visited again from there, and only the lanes
-                // whose bucket was written in between get a new candidate -- nothing else of the tile
-                // is recomputed.  The elements of a tile are written once, when the parse leaves it
-                // (masks of all its visits accumulated).  States this path does not take (a scan that
-                // may reach probe 32, the last ~128 bytes of the block) go back to the general code
-                // above/below with (P, chain, sc, next_emit) as they stand.
-                // tests/tile_model.py states the same algebra in plain integers (checked on the CPU).
-                uint32_t t = P >> 6, e = P & 63u;
-                bool c_in = true;
-                uint32_t sc_in = 0;
+                // whose bucket was written in between get a new candidate.  The elements of a tile are
+                // written once, when the parse leaves it (masks of all its visits accumulated).
+                // With kSpec the HEAD of tile t+1 (bytes, hashes, table lookups, candidate loads) is
+                // issued BEFORE tile t is walked: its lookups are speculative (tile t's inserts are not in
+                // the table yet) and are checked against the table once tile t has committed -- lanes
+                // whose bucket was written get the new candidate, the others' candidate bytes have long
+                // arrived.  States this path does not take (a scan that may reach probe 32, the last ~128
+                // bytes of the block) go back to the general code with (P, chain, sc, next_emit) as they
+                // stand.  tests/tile_model.py states the same algebra in plain integers (checked on the CPU).
+                constexpr bool kSpec = SZ_SPEC_MODE == 2 || (SZ_SPEC_MODE == 1 && Tab::kInLds);
                 first_scan = false;
-                u32x4 ta, ta2;                 // bytes [pos, pos + 32) of the lane's position
-                uint32_t th, tcand, tml = 0;   // hash, candidate as of the last lookup, match length 4..32
-                uint64_t Hraw = 0, El = 0;     // lanes whose candidate matches / whose match reaches 32 bytes
-                auto tile_head = [&](uint32_t tt, uint32_t ee, bool cc, bool pm1_done) {
+                // current tile: first dword of each position, hash, candidate (as validated), match
+                // length for the walk (4..31, or 64: reaches 32 bytes and goes on), lanes whose candidate matches
+                uint32_t t = 0, e = 0, sc_in = 0;
+                uint32_t c_in = 1;  // (flags are wave-uniform integers: the compiler keeps bools as 64-bit lane masks)
+                uint32_t a0 = 0, th = 0, tcand = 0, tmlw = 0;
+                uint64_t Hraw = 0;
+                // head of a tile whose candidate loads are in flight
+                u32x4 na = {0, 0, 0, 0}, na2 = {0, 0, 0, 0}, nc = {0, 0, 0, 0}, nc2 = {0, 0, 0, 0};
+                uint32_t nh = 0, ncand = 0, tn = 0;
+                bool have_spec = false;
+                // visits of the current tile accumulated for the element writer
+                uint64_t Vacc = 0, Hpacc = 0;
+                bool acc_open = false;
+                uint32_t acc_emit = next_emit;
+                // where the parse stands when a tile is left / entered
+                uint32_t P2 = P, sc2 = 0, long_lane = 64;
+                uint32_t chain2 = 1, pm1_done = 0, quit = 0;
+                auto head = [&](uint32_t tt) {  // bytes and hashes of tile tt
                     const uint32_t k = tt >> 1;  // buffer k = bytes [128 k, 128 k + 256) holds the tile + 32
-                    if (k != kcur) {
-                        wcur = k == kcur + 1 ? wnxt : load_buf(k);
-                        wnxt = load_buf(k + 1);
-                        kcur = k;
-                    }
+                    if (k != kcur)
+                        advance_bufs(k);
                     const uint32_t i0 = ((tt & 1u) << 6) + lane4;
                     uint32_t d[9];
 #pragma unroll
                     for (int q = 0; q < 9; q++)
                         d[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i0 + 4 * q), (int)wcur);
-                    ta.x = __builtin_amdgcn_alignbyte(d[1], d[0], lane3);
-                    ta.y = __builtin_amdgcn_alignbyte(d[2], d[1], lane3);
-                    ta.z = __builtin_amdgcn_alignbyte(d[3], d[2], lane3);
-                    ta.w = __builtin_amdgcn_alignbyte(d[4], d[3], lane3);
-                    ta2.x = __builtin_amdgcn_alignbyte(d[5], d[4], lane3);
-                    ta2.y = __builtin_amdgcn_alignbyte(d[6], d[5], lane3);
-                    ta2.z = __builtin_amdgcn_alignbyte(d[7], d[6], lane3);
-                    ta2.w = __builtin_amdgcn_alignbyte(d[8], d[7], lane3);
-                    th = (ta.x * kHashMul) >> shift;
-                    if (cc && !pm1_done) {  // the reference inserts P-1 before it looks P up
-                        if (ee >= 1) {
-                            if (lane == ee - 1)
-                                tab.put(th, (tt << 6) + lane);
-                        } else if (lane == 0) {
-                            const uint32_t pm1 = (tt << 6) - 1;
-                            tab.put((ld32(in + pm1) * kHashMul) >> shift, pm1);
-                        }
-                        asm volatile("" ::: "memory");
-                    }
-                    tcand = tab.get(th);  // all 64 positions: table as it stands
+                    na.x = __builtin_amdgcn_alignbyte(d[1], d[0], lane3);
+                    na.y = __builtin_amdgcn_alignbyte(d[2], d[1], lane3);
+                    na.z = __builtin_amdgcn_alignbyte(d[3], d[2], lane3);
+                    na.w = __builtin_amdgcn_alignbyte(d[4], d[3], lane3);
+                    na2.x = __builtin_amdgcn_alignbyte(d[5], d[4], lane3);
+                    na2.y = __builtin_amdgcn_alignbyte(d[6], d[5], lane3);
+                    na2.z = __builtin_amdgcn_alignbyte(d[7], d[6], lane3);
+                    na2.w = __builtin_amdgcn_alignbyte(d[8], d[7], lane3);
+                    nh = (na.x * kHashMul) >> shift;
+                    tn = tt;
                 };
-                // candidate bytes -> hit mask and local match lengths, for the lanes in `sel`
-                auto tile_compare = [&](uint64_t sel) {
+                auto head_loads = [&]() {
+                    nc = ld128(in + ncand);  // ncand < pos, pos + 32 <= n here
+                    nc2 = ld128(in + ncand + 16);
+                };
+                // candidates changed for the lanes in `sel` (their bucket was written after their lookup):
+                // both strings again, hit bit and match length merged in
+                auto patch = [&](uint64_t sel, uint32_t cnow) {
                     const bool on = __builtin_amdgcn_inverse_ballot_w64(sel);
-                    u32x4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+                    const uint32_t pos = (t << 6) + lane;
+                    u32x4 x = {0, 0, 0, 0}, x2 = {0, 0, 0, 0}, c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
                     if (on) {
-                        c = ld128(in + tcand);  // tcand < pos, pos + 32 <= n here
-                        c2 = ld128(in + tcand + 16);
+                        tcand = cnow;
+                        x = ld128(in + pos);
+                        x2 = ld128(in + pos + 16);
+                        c = ld128(in + cnow);
+                        c2 = ld128(in + cnow + 16);
                     }
-                    const uint32_t ml = matchlen32(ta, ta2, c, c2);
-                    const uint64_t hit = __ballot(on && c.x == ta.x);
-                    Hraw = (Hraw & ~sel) | hit;
-                    El = (El & ~sel) | (__ballot(ml == 32) & hit);
-                    tml = on ? ml : tml;
-                };
-                // elements closed inside the accumulated visits of the tile
-                uint64_t Vacc = 0, Hpacc = 0;
-                bool acc_open = false;
-                uint32_t acc_emit = next_emit;
-                auto flush_tile = [&](uint32_t tt, uint32_t long_lane) {
-                    if (Hpacc == 0)
-                        return;
-                    const uint32_t jfirst = ctz64(Hpacc);
-                    const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hpacc);
-                    uint64_t Lit = Vacc & ~Hpacc & below63(jlast);
-                    if (acc_open) {  // a literal was open when the accumulation began: it ends at the first hit
-                        emit_lit(acc_emit, (tt << 6) + jfirst - acc_emit);
-                        Lit &= ~below63(jfirst);
-                    }
-                    const uint64_t RS = Lit & ~(Lit << 1);
-                    const uint64_t HC = long_lane < 64 ? Hpacc & ~(1ull << long_lane) : Hpacc;
-                    const bool is_lit = __builtin_amdgcn_inverse_ballot_w64(Lit);
-                    const bool run_start = __builtin_amdgcn_inverse_ballot_w64(RS);
-                    const bool is_hit = __builtin_amdgcn_inverse_ballot_w64(HC);
-                    const uint32_t runlen = (uint32_t)__builtin_ctzll((Hpacc >> lane) | (1ull << 63));
-                    const uint32_t abyte = ta.x & 0xffu;
-                    const uint32_t off = (tt << 6) + lane - tcand;
-                    const bool short_form = tml < 12 && off < 2048;
-                    uint32_t cnt = 0, word = 0;
-                    if (is_lit) {
-                        cnt = run_start ? 2 : 1;
-                        word = run_start ? (((runlen - 1) << 2) | (abyte << 8)) : abyte;
-                    } else if (is_hit) {
-                        cnt = short_form ? 2 : 3;
-                        word = short_form ? (1u | ((tml - 4) << 2) | ((off >> 8) << 5) | ((off & 0xffu) << 8))
-                                          : (2u | ((tml - 1) << 2) | (off << 8));
-                    }
-                    const uint32_t incl = wave_inclusive_sum(cnt);
-                    uint8_t *o = out + (op + (incl - cnt));
-                    if (cnt >= 1) o[0] = (uint8_t)word;
-                    if (cnt >= 2) o[1] = (uint8_t)(word >> 8);
-                    if (cnt >= 3) o[2] = (uint8_t)(word >> 16);
-                    op += lane_get(incl, 63);
+                    const uint32_t ml = matchlen32(x, x2, c, c2);
+                    Hraw = (Hraw & ~sel) | ballot64(on && c.x == x.x);
+                    tmlw = on ? (ml == 32 ? 64u : ml) : tmlw;
+                    UNIFORM_JOIN();
                 };
 
                 PROF_LAP(14);
-                tile_head(t, e, true, false);
-                PROF_LAP(20);
-                tile_compare(~0ull);
-                PROF_LAPV(22);
-                for (;;) {
-                    if (++trips > 2u * kMaxBlock) {
-                        poisoned = true;
-                        break;
-                    }
-                    MARK("visit_top");
-#ifdef SZ_UNI_PROBE
-                    t = uni(t); e = uni(e); c_in = unib(c_in); sc_in = uni(sc_in); Hraw = uni64(Hraw); El = uni64(El);
-                    Vacc = uni64(Vacc); Hpacc = uni64(Hpacc); acc_open = unib(acc_open); acc_emit = uni(acc_emit);
-                    next_emit = uni(next_emit); op = uni(op); kcur = uni(kcur); trips = uni(trips);
-#endif
-                    const uint32_t pos = (t << 6) + lane;
-                    const uint64_t Hm = Hraw & ~below63(e);
-                    // ---- where the parse goes from each lane: to the next hit at or after it, then past
-                    // that hit's match (64 = out of the tile; a match that reaches 32 bytes ends the visit)
-                    const uint64_t tl = Hm >> lane;
-                    uint32_t dlo, dhi;
-                    asm("v_ffbl_b32 %0, %1" : "=v"(dlo) : "v"((uint32_t)tl));
-                    asm("v_ffbl_b32 %0, %1" : "=v"(dhi) : "v"((uint32_t)(tl >> 32)));
-                    dhi |= 32u;
-                    uint32_t dist = dlo < dhi ? dlo : dhi;  // 0xffffffff: no hit from here on
-                    dist = dist < 64u ? dist : 64u;
-                    const uint32_t nh = lane + dist;
-                    const uint32_t mlw = tml == 32 ? 64u : tml;
-                    const uint32_t m_nh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nh << 2), (int)mlw);
-                    uint32_t vJ = nh + m_nh;
-                    vJ = vJ > lane ? vJ : lane + 1;  // (always so for a hit: ml >= 4; keeps the walk finite whatever memory holds)
-                    vJ = vJ < 64u ? vJ : 64u;
-                    // ---- states left to the general code: a scan could reach probe 32 (32 hit-free lanes
-                    // in a row, or the misses carried in plus those before the first hit)
-                    const uint64_t far = __ballot(dist >= run32) & ~below63(e);
-                    const uint32_t lead = (Hm ? ctz64(Hm) : 64u) - e;
-                    if (far != 0 || (!c_in && sc_in + lead > 31)) {
-                        flush_tile(t, 64);
-                        P = (t << 6) + e;
-                        chain = c_in;
-                        sc = sc_in;
-                        hold_fast = true;
-                        break;
-                    }
-                    PROF_LAP(15);
-                    MARK("walk_loop");
-                    // ---- the serial part: one v_readlane per element
-                    uint64_t S = 0;
-                    uint32_t jj = e;
-                    do {
-                        S |= 1ull << jj;
-                        jj = lane_get(vJ, jj);
-                    } while (jj < 64);
-                    PROF_LAP(16);
-                    MARK("exit_commit");
-                    // ---- exit state for the limit `lim`, commit, check; a shared bucket repeats it once
-                    uint32_t lim = 64;
-                    uint64_t V, Hp, Ins, C;
-                    uint32_t P2, sc2, long_lane, emit2;
-                    bool chain2, pm1_done, committed = false, bad_cut = false;
-                    for (;;) {
-                        const uint64_t bl = lanes_below(lim);
-                        const uint64_t Hm_t = Hm & bl, Sx = S & bl;
-                        const uint32_t s_l = 63u - (uint32_t)__builtin_clzll(Sx);  // (lane e is in Sx)
-                        const uint64_t Hx = Hm_t >> s_l;
-                        Hp = Hm_t & ~(Hm_t - Sx);  // first hit of every segment [start, next start)
-                        long_lane = 64;
-                        emit2 = next_emit;
-                        pm1_done = false;
-                        if (Hx == 0) {  // the literal / scan is still open at lim
-                            V = (((Hp << 1) | (lim < 64 ? 1ull << lim : 0ull)) - Sx) & bl;
-                            chain2 = false;
-                            P2 = (t << 6) + lim;
-                            if (Sx == (1ull << e) && !c_in) {
-                                sc2 = sc_in + lim - e;
-                            } else {
-                                emit2 = (t << 6) + s_l;
-                                sc2 = lim - s_l - 1;
-                            }
-                        } else {
-                            V = (Hp << 1) - Sx;
-                            const uint32_t jx = s_l + ctz64(Hx);
-                            const uint32_t mj = lane_get(tml, jx);
-                            chain2 = true;
-                            sc2 = 0;
-                            P2 = (t << 6) + jx + mj;
-                            emit2 = P2;
-                            if (mj == 32)
-                                long_lane = jx;
-                            else if (lim == 64 && jx + mj == 64)
-                                pm1_done = true;  // the copy ends with the tile: its last byte is the next P-1
+                for (;;) {  // ================================================ one tile per trip
+                    // ---- (A) the elements closed inside the tile that is being left (all its visits)
+                    MARK("flush");
+                    if (Hpacc != 0) {
+                        const uint32_t jfirst = ctz64(Hpacc);
+                        const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hpacc);
+                        uint64_t Lit = Vacc & ~Hpacc & below63(jlast);
+                        if (acc_open) {
+                            // a literal was open when the accumulation began: it ends at the first hit.  It
+                            // began at a failed chain probe of this path and ends within the 32 probes a scan
+                            // makes here: one tag byte, at most 33 bytes
+                            const uint32_t len = (t << 6) + jfirst - acc_emit;
+                            if (lane == 0)
+                                out[op] = (uint8_t)((len - 1) << 2);
+                            if (lane < len)
+                                out[op + 1 + lane] = in[acc_emit + lane];
+                            UNIFORM_JOIN();
+                            poisoned = poisoned || len > 60;
+                            op += 1 + len;
+                            Lit &= ~below63(jfirst);
                         }
-                        Ins = (Sx & ~(1ull << e)) >> 1;  // the lane before each chain probe
-                        if (pm1_done)
-                            Ins |= 1ull << 63;
-                        C = V | Ins;
-                        // (every exit of this loop is taken by the whole wave, right after wave-uniform
-                        // code: a `break` behind a per-lane `if` makes the compiler treat the masks and the
-                        // state computed here as per-lane values and move them into vector registers)
-                        if (lim < 64)
-                            break;  // lanes below a cut share no bucket: committed below
-                        const bool inC = __builtin_amdgcn_inverse_ballot_w64(C);
-                        uint64_t L;
-                        if constexpr (Tab::kInLds) {
-                            uint32_t w = pos & 0xffffu;
-                            if (inC) {
-                                tab.put(th, pos);
-                                asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
-                                w = tab.get(th);
-                            }
-                            L = __ballot(inC && w != (pos & 0xffffu));
-                            committed = L == 0;
-                        } else {
-                            const uint32_t bit = 1u << (th & 31u);
-                            uint32_t old = 0;
-                            if (inC)
-                                old = __hip_atomic_fetch_or(tab.bm + (th >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            if (inC)
-                                __hip_atomic_store(tab.bm + (th >> 5), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            L = __ballot(inC && (old & bit));
+                        const uint64_t RS = Lit & ~(Lit << 1);
+                        const uint64_t HC = long_lane < 64 ? Hpacc & ~(1ull << long_lane) : Hpacc;
+                        const bool is_lit = __builtin_amdgcn_inverse_ballot_w64(Lit);
+                        const bool run_start = __builtin_amdgcn_inverse_ballot_w64(RS);
+                        const bool is_hit = __builtin_amdgcn_inverse_ballot_w64(HC);
+                        const uint32_t runlen = (uint32_t)__builtin_ctzll((Hpacc >> lane) | (1ull << 63));
+                        const uint32_t abyte = a0 & 0xffu;
+                        const uint32_t off = (t << 6) + lane - tcand;
+                        const bool short_form = tmlw < 12 && off < 2048;
+                        uint32_t cnt = 0, word = 0;
+                        if (is_lit) {
+                            cnt = run_start ? 2 : 1;
+                            word = run_start ? (((runlen - 1) << 2) | (abyte << 8)) : abyte;
+                        } else if (is_hit) {
+                            cnt = short_form ? 2 : 3;
+                            word = short_form ? (1u | ((tmlw - 4) << 2) | ((off >> 8) << 5) | ((off & 0xffu) << 8))
+                                              : (2u | ((tmlw - 1) << 2) | (off << 8));
                         }
-                        if (L == 0)
-                            break;
-                        if constexpr (Tab::kInLds) {
-                            asm volatile("" ::: "memory");
-                            if (inC)
-                                tab.put(th, tcand);  // roll back (lanes of one bucket hold the same old entry)
-                        }
-                        uint32_t cut = 64;
-                        while (L) {
-                            const uint32_t hv = lane_get(th, ctz64(L));
-                            const uint64_t G = __ballot(inC && th == hv);
-                            L &= ~G;
-                            const uint64_t G2 = G & (G - 1);
-                            const uint32_t second = ctz64(G2);
-                            cut = second < cut ? second : cut;
-                        }
-                        // (cut <= e or no cut at all cannot happen: a lost write that no shared bucket
-                        // explains.  The block is poisoned below instead of looping on it.)
-                        bad_cut = cut <= e || cut >= 64;
-                        lim = bad_cut ? e + 1 : cut;
+                        const uint32_t incl = wave_inclusive_sum(cnt);
+                        uint8_t *o = out + (op + (incl - cnt));
+                        if (cnt >= 1) o[0] = (uint8_t)word;
+                        if (cnt >= 2) o[1] = (uint8_t)(word >> 8);
+                        if (cnt >= 3) o[2] = (uint8_t)(word >> 16);
+                        UNIFORM_JOIN();
+                        op += lane_get(incl, 63);
                     }
-                    if (!committed) {  // the final set of inserts (below a cut, or a global-memory table)
-                        if (__builtin_amdgcn_inverse_ballot_w64(C))
-                            tab.put(th, pos);
-                    }
-                    poisoned = poisoned || bad_cut;
-                    if (poisoned)
-                        break;
-                    PROF_LAP(17);
-                    MARK("after_commit");
-                    next_emit = emit2;
-                    Vacc |= V;
-                    Hpacc |= Hp;
+                    PROF_LAP(21);
                     if (long_lane < 64) {  // the last hit's match runs past its 32 local bytes: finish it
-                        flush_tile(t, long_lane);
                         const uint32_t ip = (t << 6) + long_lane, cnd = lane_get(tcand, long_lane);
                         const uint32_t m = match_length(in, cnd, ip, n, lane, 32);
                         op = emit_copy(out, op, ip - cnd, m, lane);
                         P2 = ip + m;
                         next_emit = P2;
-                        Vacc = 0;
-                        Hpacc = 0;
-                        acc_open = false;
-                        acc_emit = P2;
+                        chain2 = 1;
+                        sc2 = 0;
+                        pm1_done = 0;
+                        long_lane = 64;
+                        PROF_LAPV(18);
+                    }
+                    if (quit || poisoned)
+                        break;
+                    // ---- (B) enter the tile of P2
+                    MARK("enter");
+                    if (P2 + kFastMargin > ip_limit) {
+                        P = P2;
+                        chain = chain2 != 0;
+                        sc = sc2;
+                        break;
                     }
                     const uint32_t t2 = P2 >> 6, e2 = P2 & 63u;
-                    PROF_LAPV(18);
-                    MARK("next_tile");
-                    if (t2 != t) {
-                        const bool go_on = P2 + kFastMargin <= ip_limit;
-                        const u32x4 oa = ta;  // the tile being left: its elements go out under the new tile's loads
-                        const uint32_t ocand = tcand, oml = tml;
-                        MARK("head");
-                        if (go_on)
-                            tile_head(t2, e2, chain2, pm1_done);
-                        PROF_LAP(20);
-                        MARK("flush");
-                        {
-                            const u32x4 na = ta;
-                            const uint32_t ncand = tcand;
-                            ta = oa;
-                            tcand = ocand;
-                            flush_tile(t, 64);
-                            ta = na;
-                            tcand = ncand;
-                            (void)oml;
+                    uint64_t stale = 0;
+                    uint32_t cnow = 0;
+                    if (kSpec && have_spec && t2 == tn) {
+                        // the head issued ahead is this tile: check its lookups against the table
+                        cnow = tab.get(nh);
+                        stale = ballot64(cnow != ncand);
+                        if (chain2 && !pm1_done) {  // P-1 goes in first: the lanes of its bucket then see it
+                            // (P-1 is lane e2-1 of the new tile, or -- a copy that ended with the old tile
+                            // behind a cut or a long match -- lane 63 of the old one)
+                            const uint32_t hp = e2 >= 1 ? lane_get(nh, e2 - 1) : lane_get(th, 63);
+                            const uint64_t same = ballot64(nh == hp) & ~below63(e2);
+                            stale |= same;
+                            cnow = __builtin_amdgcn_inverse_ballot_w64(same) ? P2 - 1 : cnow;
+                            if (lane == 0)
+                                tab.put(hp, P2 - 1);
+                            UNIFORM_JOIN();
                         }
-                        Vacc = 0;
-                        Hpacc = 0;
-                        acc_open = !chain2;
-                        acc_emit = next_emit;
-                        if (!go_on) {
-                            P = P2;
-                            chain = chain2;
-                            sc = sc2;
-                            break;
-                        }
-                        t = t2;
-                        PROF_LAP(21);
-                        MARK("compare");
-                        tile_compare(~0ull);
-                        MARK("compare_end");
-                        PROF_LAPV(22);
                     } else {
-                        // the same tile again (after a cut or a long match): insert P-1, then give the lanes
-                        // whose bucket was written since their lookup the new candidate
-                        if (chain2 && lane == e2 - 1)
-                            tab.put(th, pos);
-                        asm volatile("" ::: "memory");
-                        const uint32_t cnow = tab.get(th);
-                        const uint64_t stale = __ballot(cnow != tcand) & ~below63(e2);
-                        if (stale) {
-                            tcand = __builtin_amdgcn_inverse_ballot_w64(stale) ? cnow : tcand;
-                            tile_compare(stale);
+                        head(t2);
+                        if (chain2 && !pm1_done) {  // the reference inserts P-1 before it looks P up
+                            if (e2 >= 1) {
+                                if (lane == e2 - 1)
+                                    tab.put(nh, P2 - 1);
+                            } else if (lane == 0) {
+                                tab.put((ld32(in + P2 - 1) * kHashMul) >> shift, P2 - 1);
+                            }
+                            asm volatile("" ::: "memory");
                         }
-                        PROF_LAPV(23);
+                        ncand = tab.get(nh);
+                        head_loads();
                     }
+                    PROF_LAP(20);
+                    MARK("compare");
+                    {  // the head becomes the current tile: compare -> hit mask, match lengths
+                        const uint32_t ml = matchlen32(na, na2, nc, nc2);
+                        Hraw = ballot64(nc.x == na.x);
+                        tmlw = ml == 32 ? 64u : ml;
+                        a0 = na.x;
+                        th = nh;
+                        tcand = ncand;
+                        t = tn;
+                    }
+                    PROF_LAPV(22);
+                    if (stale)
+                        patch(stale, cnow);
+                    PROF_LAPV(24);
+                    Vacc = 0;
+                    Hpacc = 0;
+                    acc_open = chain2 == 0;
+                    acc_emit = next_emit;
                     e = e2;
                     c_in = chain2;
                     sc_in = sc2;
-                    PROF_LAP(19);
-                    MARK("visit_end");
+                    const uint32_t base = t << 6;
+                    const uint32_t pos = base + lane;
+                    // ---- (C) head of the next tile, ahead of this tile's walk (lookups checked afterwards)
+                    have_spec = kSpec && base + 64 + kFastMargin <= ip_limit;
+                    if (have_spec) {
+                        head(t + 1);
+                        ncand = tab.get(nh);
+                        head_loads();
+                    }
+                    PROF_LAP(25);
+                    for (;;) {  // ============================================ visits of this tile
+                        // (every visit ends beyond its entry lane, every tile beyond the one before: no trip count)
+                        MARK("visit_top");
+                        const uint64_t Hm = Hraw & ~below63(e);
+                        // ---- where the parse goes from each lane: to the next hit at or after it, then
+                        // past that hit's match (64 = out of the tile; a match that reaches 32 bytes ends
+                        // the visit)
+                        const uint64_t tl = Hm >> lane;
+                        uint32_t dlo, dhi;
+                        asm("v_ffbl_b32 %0, %1" : "=v"(dlo) : "v"((uint32_t)tl));
+                        asm("v_ffbl_b32 %0, %1" : "=v"(dhi) : "v"((uint32_t)(tl >> 32)));
+                        const uint32_t dist = umin3(dlo, dhi | 32u, 64u);  // 64: no hit from here on
+                        const uint32_t nh_l = lane + dist;
+                        const uint32_t m_nh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nh_l << 2), (int)tmlw);
+                        uint32_t vJ = nh_l + m_nh;
+                        vJ = vJ > lane ? vJ : lane + 1;  // (always so for a hit: ml >= 4; keeps the walk finite whatever memory holds)
+                        vJ = vJ < 64u ? vJ : 64u;
+                        // ---- states left to the general code: a scan could reach probe 32 (32 hit-free
+                        // lanes in a row, or the misses carried in plus those before the first hit)
+                        const uint64_t far = ballot64(dist >= run32) & ~below63(e);
+                        const uint32_t lead = ctz64(Hm | (1ull << 63)) - e;
+                        const uint32_t lead_bad = (c_in ^ 1u) & (sc_in + lead > 31 ? 1u : 0u);
+                        if ((far != 0) | (lead_bad != 0)) {
+                            P = base + e;
+                            chain = c_in != 0;
+                            sc = sc_in;
+                            hold_fast = true;
+                            quit = 1;
+                            break;
+                        }
+                        PROF_LAP(15);
+                        MARK("walk_loop");
+                        // ---- the serial part: one v_readlane per element
+                        uint64_t S = 0;
+                        uint32_t jj = e;
+                        do {
+                            S |= 1ull << jj;
+                            jj = lane_get(vJ, jj);
+                        } while (jj < 64);
+                        PROF_LAP(16);
+                        MARK("exit_commit");
+                        // ---- exit state, commit, check.  Common case first (no two inserted lanes share
+                        // a bucket: lim = 64); a shared bucket repeats the exit computation for lim = cut.
+                        uint64_t V, Hp, C;
+                        uint32_t ll, emit2;
+                        // (selects of wave-uniform integers, no branches: the compiler then keeps all of
+                        // it in scalar registers without copies where branch arms would meet)
+                        auto exit_for = [&](uint32_t lim) {
+                            const uint64_t bl = lanes_below(lim);
+                            const uint64_t Hm_t = Hm & bl, Sx = S & bl;
+                            const uint32_t s_l = 63u - (uint32_t)__builtin_clzll(Sx);  // (lane e is in Sx)
+                            const uint64_t Hx = Hm_t >> s_l;
+                            const uint32_t open = Hx == 0 ? 1u : 0u;  // the literal / scan is still open at lim
+                            Hp = Hm_t & ~(Hm_t - Sx);  // first hit of every segment [start, next start)
+                            const uint64_t bitlim = lim < 64 ? 1ull << lim : 0ull;
+                            V = (((Hp << 1) | (open ? bitlim : 0ull)) - Sx) & bl;
+                            const uint32_t jx = (s_l + ctz64(Hx | (1ull << 63))) & 63u;  // the last hit on the path
+                            const uint32_t mj = lane_get(tmlw, jx);
+                            const uint32_t carried = (Sx == (1ull << e) ? 1u : 0u) & (c_in ^ 1u);
+                            const uint32_t is_long = (open ^ 1u) & (mj == 64 ? 1u : 0u);
+                            const uint32_t pend = base + jx + mj;  // where the last copy ends
+                            chain2 = open ^ 1u;
+                            ll = is_long ? jx : 64u;  // (the long match is finished at (A))
+                            P2 = open ? base + lim : (is_long ? base + jx : pend);
+                            sc2 = open ? (carried ? sc_in + lim - e : lim - s_l - 1) : 0u;
+                            emit2 = open ? (carried ? next_emit : base + s_l) : pend;
+                            // the copy ends with the tile: its last byte is the next P-1
+                            pm1_done = (open ^ 1u) & (is_long ^ 1u) & (lim == 64 ? 1u : 0u) & (jx + mj == 64 ? 1u : 0u);
+                            const uint64_t Ins = ((Sx & ~(1ull << e)) >> 1) | ((uint64_t)pm1_done << 63);  // the lane before each chain probe
+                            C = V | Ins;
+                        };
+                        exit_for(64);
+                        {
+                            const bool inC = __builtin_amdgcn_inverse_ballot_w64(C);
+                            uint64_t L;
+                            if constexpr (Tab::kInLds) {
+                                uint32_t w = pos & 0xffffu;
+                                if (inC) {
+                                    tab.put(th, pos);
+                                    asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
+                                    w = tab.get(th);
+                                }
+                                L = ballot64(inC && w != (pos & 0xffffu));
+                            } else {
+                                const uint32_t bit = 1u << (th & 31u);
+                                uint32_t old = 0;
+                                if (inC)
+                                    old = __hip_atomic_fetch_or(tab.bm + (th >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                if (inC)
+                                    __hip_atomic_store(tab.bm + (th >> 5), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                L = ballot64(inC && (old & bit) != 0);
+                            }
+                            if (L != 0) {  // two inserted lanes share a bucket: end the visit before the second one
+                                if constexpr (Tab::kInLds) {
+                                    asm volatile("" ::: "memory");
+                                    if (inC)
+                                        tab.put(th, tcand);  // roll back (lanes of one bucket hold the same old entry)
+                                }
+                                uint32_t cut = 64;
+                                while (L) {
+                                    const uint32_t hv = lane_get(th, ctz64(L));
+                                    const uint64_t G = ballot64(inC && th == hv);
+                                    L &= ~G;
+                                    const uint64_t G2 = G & (G - 1);
+                                    const uint32_t second = ctz64(G2);
+                                    cut = second < cut ? second : cut;
+                                }
+                                // (cut <= e or no cut at all cannot happen: a lost write that no shared
+                                // bucket explains.  The block is poisoned instead of looping on it.)
+                                const bool bad_cut = cut <= e || cut >= 64;
+                                poisoned = poisoned || bad_cut;
+                                exit_for(bad_cut ? e + 1 : cut);
+                                if (__builtin_amdgcn_inverse_ballot_w64(C))
+                                    tab.put(th, pos);  // lanes below a cut share no bucket
+                                UNIFORM_JOIN();
+                            } else if constexpr (!Tab::kInLds) {
+                                if (inC)
+                                    tab.put(th, pos);
+                                UNIFORM_JOIN();
+                            }
+                        }
+                        if (poisoned)
+                            break;
+                        PROF_LAP(17);
+                        MARK("after_commit");
+                        next_emit = emit2;
+                        Vacc |= V;
+                        Hpacc |= Hp;
+                        if (ll < 64) {
+                            long_lane = ll;
+                            break;
+                        }
+                        if ((P2 >> 6) != t)
+                            break;
+                        // the same tile again (after a cut): insert P-1, then give the lanes whose bucket
+                        // was written since their lookup the new candidate
+                        const uint32_t e2s = P2 & 63u;
+                        if (chain2 && lane == e2s - 1)
+                            tab.put(th, pos);
+                        asm volatile("" ::: "memory");
+                        const uint32_t cn = tab.get(th);
+                        const uint64_t st = ballot64(cn != tcand) & ~below63(e2s);
+                        if (st)
+                            patch(st, cn);
+                        PROF_LAPV(23);
+                        e = e2s;
+                        c_in = chain2;
+                        sc_in = sc2;
+                        MARK("visit_end");
+                    }
                 }
                 if (!chain)
                     scan_base = P - sc;
@@ -1027,6 +1120,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         if (L == 0) {
                             if (ins_lane)
                                 tab.put(h, pos);
+                            UNIFORM_JOIN();
                             break;
                         }
                     }
@@ -1109,6 +1203,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     if (cnt >= 2) o[1] = (uint8_t)(word >> 8);
                     if (cnt >= 3) o[2] = (uint8_t)(word >> 16);
                     }
+                    UNIFORM_JOIN();
                     op += lane_get(incl, 63);
                 }
                 PROF_LAP(4);
@@ -1182,6 +1277,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 }
                 if (valid && lane < cut)
                     tab.put(h, p);
+                UNIFORM_JOIN();
             }
             const uint32_t nact = nvalid < cut ? nvalid : cut;
             const bool act = lane < nact;

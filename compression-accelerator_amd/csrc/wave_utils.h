@@ -45,6 +45,9 @@ __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l)
     return __builtin_amdgcn_readlane(v, uni(l));
 }
 __device__ __forceinline__ uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
+// ballot of a per-lane condition (the HIP __ballot takes an int: the condition would go through a
+// 0/1 vector register and a second compare)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // dword at byte offset `off` of a block of n bytes; bytes past the end read as 0 (never touched)
 __device__ __forceinline__ uint32_t ld32_clamped(const uint8_t *in, uint32_t off, uint32_t n)

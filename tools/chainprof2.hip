@@ -27,7 +27,7 @@ int main(int argc, char **argv)
     const char *names[32] = {"window load+hash", "table lookup issue", "cand loads+compare", "walk+commit+verify", "emit", "long match",
                              "strided batch", "strided hit", "walk (per pass)", "commit+readback (per pass)", "lim", "cut windows", "hits/window", "advance/window",
                              "F: enter (since last lap)", "F: visit top + walk prep", "F: walk loop", "F: exit + commit", "F: next/long (vm drained)", "F: visit end",
-                             "F: tile head", "F: flush", "F: compare (vm drained)", "F: same-tile validate", "", "", "", "", "", "", "", ""};
+                             "F: spec head / validate", "F: flush", "F: compare (vm drained)", "F: same-tile validate", "F: stale patch after adopt", "F: fresh head+adopt", "", "", "", "", "", ""};
     for (int rep = 0; rep < 2; rep++) {
         unsigned long long z[128] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(szk::g_prof), z, sizeof z);
@@ -43,11 +43,11 @@ int main(int argc, char **argv)
                 const unsigned long long *q = p + 64 * t;
                 unsigned long long tot = 0;
                 for (int i = 0; i < 10; i++) tot += q[i];
-                for (int i = 14; i < 24; i++) tot += q[i];
+                for (int i = 14; i < 26; i++) tot += q[i];
                 printf("--- %s waves: %llu windows + %llu tiles (%llu visits), %.0f ticks in all\n", t ? "GLOBAL-table" : "LDS-table", q[32 + 3], q[32 + 21], q[32 + 15], (double)tot);
                 for (int i = 0; i < 32; i++)
                     if (q[32 + i])
-                        printf("  %-28s total %12llu  count %9llu  avg %8.2f  (%4.1f%%)\n", names[i], q[i], q[32 + i], (double)q[i] / q[32 + i], (i < 10 || (i >= 14 && i < 24)) ? 100.0 * q[i] / tot : 0.0);
+                        printf("  %-28s total %12llu  count %9llu  avg %8.2f  (%4.1f%%)\n", names[i], q[i], q[32 + i], (double)q[i] / q[32 + i], (i < 10 || (i >= 14 && i < 26)) ? 100.0 * q[i] / tot : 0.0);
             }
         }
     }

@@ -8,6 +8,8 @@ import torch
 import bench
 from pkg_loader import load_package
 P = load_package()
+if os.environ.get("SZ_AB_LIB"):  # A/B experiments: another build of the library
+    P.LIB_PATH = os.path.join(ROOT, os.environ["SZ_AB_LIB"])
 kind = sys.argv[1]; nb = int(sys.argv[2]) if len(sys.argv) > 2 else 4096; reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device("cuda:0")
 src = bench.make_input(kind, 0, nb, dev)
