@@ -5,21 +5,27 @@
 
 A "step" is one pass of the hot path (sz_compress_blocks_hip through the C ABI) over this rank's
 blocks, input already resident in HBM, plus -- for N>1 -- the RCCL all_gather of the per-block
-lengths.  Prints ONE JSON line on rank 0.  N>1 is launched by torch.distributed.run (one process
-per GPU); blocks shard by contiguous ranges, weak scaling (fixed blocks per GPU).
+lengths.  Prints ONE JSON line on rank 0.  Blocks shard by contiguous ranges, weak scaling (fixed
+blocks per GPU), one process per GPU.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>`) as a CHILD
+process before anything here has touched the GPU, relays rank 0's line and exits with the child's
+code.  Under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 
 Headline workload (config.workload): C3 = consecutive 64 KiB windows of the infinite tiling of
 data/randomASCII.txt (BASELINE.json configs[2], the one the north-star target is quoted on);
 --blocks-per-gpu 32768 (2 GiB per GPU) so that N=8 is config C4's 16 GiB.  Short passes over the
 text (C2-like), low-entropy (C5) and mixed (C4 mix) workloads are reported in "workloads".
+Every block of every pass is compared with the oracle after the timed region.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -28,8 +34,62 @@ BLOCK = 65536
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c3", "text", "c5", "mix"])
+    ap.add_argument("--blocks-per-gpu", type=int, default=32768)
+    ap.add_argument("--no-extra", action="store_true", help="skip the short text/c5/mix passes")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl = RCCL) even with one rank: rehearsal of the N>1 path")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------- launcher (no GPU call)
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, script, script_args, env=None, timeout=None):
+    """Starts n ranks of `script` under torch.distributed.run on this node as a child process (never
+    an exec: a process that has initialised the GPU must not be replaced, and this one stays clean
+    anyway), relays the child's stdout/stderr and returns (exit code, the last JSON line printed)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(script_args)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this pool)
+    p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            line = ln
+    return p.returncode, line, p.stdout, p.stderr
+
+
+def layout_fields(gathered, offsets, local_lens, rank, blocks_per_rank):
+    """What rank 0 reports about the one collective of the path: how many ranks' lengths arrived, and
+    whether the gathered layout is the one every rank would pack with (ends at the total; this
+    rank's slice of it is this rank's own lengths).  Tensors on any device."""
+    import torch
+    n = int(gathered.numel())
+    ok = (int(offsets[-1].item()) == int(gathered.to(torch.int64).sum().item())
+          and bool(torch.equal(gathered[rank * blocks_per_rank:(rank + 1) * blocks_per_rank], local_lens)))
+    return {"rccl_ranks_seen": n // blocks_per_rank if blocks_per_rank else 0, "gathered_layout_ok": ok}
+
+
+# ------------------------------------------------------------------------------- inputs (on device)
+
 def make_input(kind, first_block, n_blocks, device):
     """Builds this rank's blocks [first_block, first_block+n_blocks) directly in HBM."""
+    import numpy as np
     import torch
     import fuzzgen
 
@@ -63,11 +123,14 @@ def make_input(kind, first_block, n_blocks, device):
     raise KeyError(kind)
 
 
-def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on, verify_blocks=8, decompress=False):
+# ------------------------------------------------------------------------------------ one workload
+
+def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on, decompress=False):
     """Returns dict with timing of `steps` steps (max over ranks), kernel-only event times, sizes."""
+    import numpy as np
     import torch
     import torch.distributed as dist
-    import oracle_lib
+    import parity_util
     from compression_accelerator_amd import sharding as shard
 
     src = make_input(kind, first_block, n_blocks, device)
@@ -77,7 +140,6 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
     # Two sets of length buffers: the all_gather + scan of step i run on a side stream under the
     # compression of step i+1 (the collective is latency-bound: 128 KiB per rank).
     out_lens = [torch.zeros(n_blocks, dtype=torch.int32, device=device) for _ in range(2)]
-    out_len = out_lens[0]
     if dist_on:
         comm = torch.cuda.Stream(device)
         gathered = [torch.empty(n_total, dtype=torch.int32, device=device) for _ in range(2)]
@@ -118,31 +180,21 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    last = (warmup + steps - 1) & 1 if steps + warmup > 0 else 0
+    layout = None
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the gathered layout is what every rank would pack with: ends at the total, and this rank's
-        # slice of it is this rank's own lengths (reported, not asserted: a bench line beats a traceback)
-        kk = (warmup + steps - 1) & 1
-        r = dist.get_rank()
-        layout_ok = (int(offs[kk][-1].item()) == int(gathered[kk].sum().item())
-                     and bool(torch.equal(gathered[kk][r * n_blocks:(r + 1) * n_blocks], out_lens[kk])))
-    else:
-        layout_ok = None
-    out_len = out_lens[(warmup + steps - 1) & 1] if steps + warmup > 0 else out_lens[0]
+        # (reported, not asserted: a bench line beats a traceback)
+        layout = layout_fields(gathered[last], offs[last], out_lens[last], dist.get_rank(), n_blocks)
+    out_len = out_lens[last]
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
-    # ---- checks, outside the timed region: sample blocks against the oracle, all lengths sane
+    # ---- checks, outside the timed region: EVERY block against the oracle (bytes and lengths)
     lens = out_len.cpu().numpy().astype(np.int64)
     out_bytes = int(lens.sum())
-    pick = np.unique(np.linspace(0, n_blocks - 1, verify_blocks).astype(np.int64))
-    host_in = src.reshape(n_blocks, BLOCK)[torch.from_numpy(pick).to(device)].cpu().numpy()
-    host_out = dst.reshape(n_blocks, P.SLOT_STRIDE)[torch.from_numpy(pick).to(device)].cpu().numpy()
-    exact = True
-    for j, b in enumerate(pick):
-        want = oracle_lib.raw_compress(host_in[j])
-        exact &= host_out[j, :lens[b]].tobytes() == want
+    bad, first_bad = parity_util.count_mismatching_blocks(src, dst, out_len, n_blocks, P.SLOT_STRIDE)
     # ---- the next row: GPU decompression of what was just produced, round trip checked
     dec = None
     if decompress:
@@ -158,28 +210,72 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
         del back
     del src, dst
     return {"elapsed_s": elapsed, "kernel_ms": kernel_ms, "in_bytes": n_blocks * BLOCK, "out_bytes": out_bytes,
-            "bit_exact_sample": bool(exact), "n_blocks": n_blocks, "decompress": dec, "gathered_layout_ok": layout_ok}
+            "blocks_differing_from_oracle": bad, "first_bad_block": first_bad, "n_blocks": n_blocks,
+            "decompress": dec, "layout": layout}
 
 
-def cpu_baseline(kind, sample_blocks, budget_s=12.0):
-    """The oracle (kind "port": bit-exact CPU restatement of Snappy 1.1.8) on the host cores,
-    bounded sample of the same workload."""
-    import torch
+# -------------------------------------------------------------------------------------- CPU baseline
+
+def effective_cores():
+    """CPUs this process may really use: the affinity set, capped by the cgroup CPU quota (a GPU box
+    shows all of the host's logical CPUs in the affinity mask while the container owns a share)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
+def host_cpu():
+    model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    cores, quota = effective_cores()
+    return {"model": model, "os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+            "cgroup_cpu_quota": quota, "threads_used": cores}
+
+
+def cpu_baseline(kind, sample_blocks, budget_s=10.0):
+    """The oracle (kind "port": bit-exact CPU restatement of Snappy 1.1.8) on the host cores, on a
+    bounded sample of the same workload: pinned pthreads created once, buffers allocated before the
+    clock starts, one warm-up pass, then >= 20 timed passes (oracle_time_compress_blocks; the
+    reference's own loop is workloads/snappy/overlay/root/compress.cc:26-34)."""
     import oracle_lib
     src = make_input(kind, 0, sample_blocks, "cpu").numpy()
-    cores = min(len(os.sched_getaffinity(0)), 16)  # the box's CPU share for one GPU
+    cores, _ = effective_cores()  # the box's real CPU share
+    cores = max(1, min(cores, sample_blocks // 8))  # (every thread gets a few blocks)
     res = {}
     for threads in (1, cores):
-        n_pass, t_used = 0, 0.0
-        while t_used < budget_s / 2 and n_pass < 50:
-            t0 = time.perf_counter()
-            oracle_lib.compress_blocks(src, BLOCK, sample_blocks, per_block_varint=True, threads=threads)
-            t_used += time.perf_counter() - t0
-            n_pass += 1
-        res[threads] = sample_blocks * BLOCK * n_pass / t_used / 1e9
-    out = {"value": round(res[cores], 3), "unit": "GB/s", "cores": cores, "kind": "port",
-           "single_thread_GBps": round(res[1], 3),
-           "sample": "%d x 64 KiB blocks of workload %s, oracle/snappy_oracle.c, %d pthreads" % (sample_blocks, kind, cores)}
+        sec1, _ = oracle_lib.time_compress_blocks(src, BLOCK, sample_blocks, threads, 1)
+        reps = max(20, min(2000, int((budget_s / 2) / max(sec1, 1e-6))))
+        if sec1 * 20 > budget_s:  # a slow sample: keep the run bounded, say so
+            reps = max(3, int(budget_s / 2 / sec1))
+        sec, _ = oracle_lib.time_compress_blocks(src, BLOCK, sample_blocks, threads, reps)
+        res[threads] = (sample_blocks * BLOCK * reps / sec / 1e9, reps)
+    out = {"value": round(res[cores][0], 3), "unit": "GB/s", "cores": cores, "kind": "port",
+           "single_thread_GBps": round(res[1][0], 3), "passes": {"1_thread": res[1][1], "%d_threads" % cores: res[cores][1]},
+           "host": host_cpu(),
+           "sample": "%d x 64 KiB blocks of workload %s, oracle/snappy_oracle.c, %d pinned pthreads, preallocated buffers, "
+                     "1 warm-up + timed passes" % (sample_blocks, kind, cores)}
     lib = _system_libsnappy()
     if lib is not None:  # informational: the real google/snappy of this image, if there is one (BASELINE.md section 4)
         out["system_libsnappy"] = _time_libsnappy(lib, src, sample_blocks, cores, budget_s / 2)
@@ -206,9 +302,11 @@ def _time_libsnappy(lib, src, sample_blocks, cores, budget_s):
     from concurrent.futures import ThreadPoolExecutor
     cap = lib.snappy_max_compressed_length(BLOCK)
     base = src.ctypes.data
+    bufs = [ctypes.create_string_buffer(cap) for _ in range(cores)]  # one output buffer per thread, reused
 
-    def work(rng):
-        buf = ctypes.create_string_buffer(cap)
+    def work(args):
+        t, rng = args
+        buf = bufs[t]
         n = ctypes.c_size_t(0)
         for b in rng:
             n.value = cap
@@ -216,32 +314,25 @@ def _time_libsnappy(lib, src, sample_blocks, cores, budget_s):
 
     res = {}
     for threads in (1, cores):
-        chunks = [range(t, sample_blocks, threads) for t in range(threads)]
+        chunks = [(t, range(t, sample_blocks, threads)) for t in range(threads)]
         n_pass, t_used = 0, 0.0
         with ThreadPoolExecutor(threads) as ex:
-            while t_used < budget_s / 2 and n_pass < 50:
+            list(ex.map(work, chunks))  # warm-up
+            while (t_used < budget_s / 2 or n_pass < 3) and n_pass < 200:
                 t0 = time.perf_counter()
                 list(ex.map(work, chunks))
                 t_used += time.perf_counter() - t0
                 n_pass += 1
         res[threads] = sample_blocks * BLOCK * n_pass / t_used / 1e9
     return {"library": lib._path, "single_thread_GBps": round(res[1], 3), "threads": cores,
-            "threads_GBps": round(res[cores], 3), "note": "version of the image's libsnappy; bytes equal the oracle's only for 1.1.8"}
+            "threads_GBps": round(res[cores], 3),
+            "note": "version of the image's libsnappy (called per block through ctypes); bytes equal the oracle's only for 1.1.8"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c3", "text", "c5", "mix"])
-    ap.add_argument("--blocks-per-gpu", type=int, default=32768)
-    ap.add_argument("--no-extra", action="store_true", help="skip the short text/c5/mix passes")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed (nccl = RCCL) even with one rank: rehearsal of the N>1 path")
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------------------- one rank
 
+def rank_main(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
     from pkg_loader import load_package
@@ -259,10 +350,12 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    props = torch.cuda.get_device_properties(device)
+    if "gfx950" not in getattr(props, "gcnArchName", "gfx950") and rank == 0:
+        print("note: device %s is not gfx950; the roofline peak below is MI355X's" % props.name, file=sys.stderr)
 
     B = args.blocks_per_gpu
-    first = rank * B
-    main_res = run_workload(P, args.workload, first, B, args.steps, args.warmup, device, dist_on)
+    main_res = run_workload(P, args.workload, rank * B, B, args.steps, args.warmup, device, dist_on)
 
     extras = {}
     if not args.no_extra:
@@ -275,15 +368,17 @@ def main():
                             "kernel_ms": round(k_ms, 3), "blocks_per_gpu": nb,
                             "compression_ratio": round(r["in_bytes"] / r["out_bytes"], 4),
                             "hbm_frac_in_plus_out": round((r["in_bytes"] + r["out_bytes"]) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                            "bit_exact_sample": r["bit_exact_sample"],
+                            "blocks_differing_from_oracle": r["blocks_differing_from_oracle"],
                             "gpu_decompress_GBps": round(r["in_bytes"] / (r["decompress"]["ms"] * 1e-3) / 1e9, 2),
                             "gpu_round_trip": r["decompress"]["round_trip"]}
+            if r["layout"] is not None:
+                extras[kind].update(r["layout"])
 
-    exact_all = main_res["bit_exact_sample"]
+    bad_all = main_res["blocks_differing_from_oracle"] + sum(v["blocks_differing_from_oracle"] for v in extras.values())
     if dist_on:
-        t = torch.tensor([1 if exact_all else 0], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        exact_all = bool(t.item())
+        t = torch.tensor([bad_all], device=device, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        bad_all = int(t.item())
 
     if rank == 0:
         K = args.steps
@@ -307,29 +402,50 @@ def main():
                        + ", %d x 64 KiB blocks per GPU (%.2f GiB/GPU)" % (B, B * BLOCK / 2**30),
                        "blocks_per_gpu": B, "block_bytes": BLOCK,
                        "kernel": os.environ.get("SZ_KERNEL", "auto (sampled: single for incompressible, dual otherwise)"),
-                       "sharding": "contiguous block ranges, no data-path collective; all_gather of uint32 lengths over RCCL"},
-            "compressed_size_ratio_vs_ref": 1.0 if exact_all else None,
-            "bit_exact_vs_oracle_sample": exact_all,
+                       "sharding": "contiguous block ranges, no data-path collective; all_gather of uint32 lengths over RCCL",
+                       "device": props.name},
+            "compressed_size_ratio_vs_ref": 1.0 if bad_all == 0 else None,
+            "bit_exact_vs_oracle_all_blocks": bad_all == 0,
+            "blocks_differing_from_oracle": bad_all,
             "compression_ratio": round(main_res["in_bytes"] / main_res["out_bytes"], 5),
             "input_frac_of_hbm_peak": round(main_res["in_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": int(traffic) if traffic else None,
                          "kernel": "szk::compress_blocks_kernel", "kernel_ms_avg": round(k_ms, 4),
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "peak_source": "MI355X HBM3E spec (MI355X_MICROARCH.md); device reports %s, %d CUs"
+                                        % (props.name, props.multi_processor_count)},
             "workloads": extras,
         }
-        if main_res.get("gathered_layout_ok") is not None:
-            line["gathered_layout_ok"] = main_res["gathered_layout_ok"]  # rank 0's view of the all_gather result
+        if main_res["layout"] is not None:
+            line.update(main_res["layout"])  # rank 0's view of the all_gather result
         if not args.no_cpu and world == 1:  # host baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.workload, 1024)
-            if "text" in extras:  # the same oracle on the latency-bound workload, for scale (bounded: ~4 s)
-                t = cpu_baseline("text", 256, budget_s=4.0)
-                extras["text"]["cpu_port_GBps"] = {"1_thread": t["single_thread_GBps"], "%d_threads" % t["cores"]: t["value"]}
+            for kind, nb_s, budget in (("text", 256, 6.0), ("c5", 512, 3.0), ("mix", 384, 4.0)):
+                if kind in extras:  # the same oracle on the other reported workloads (bounded)
+                    t = cpu_baseline(kind, nb_s, budget_s=budget)
+                    extras[kind]["cpu_baseline"] = {k: t[k] for k in ("value", "unit", "cores", "kind", "single_thread_GBps", "sample")}
+                    if "system_libsnappy" in t:
+                        extras[kind]["cpu_baseline"]["system_libsnappy"] = t["system_libsnappy"]
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the ranks as a child process; nothing in THIS process has touched the GPU
+        rc, line, out, err = launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+        sys.stderr.write(err)
+        if line is not None:
+            print(line, flush=True)
+        else:
+            sys.stdout.write(out)
+        raise SystemExit(rc)
+    rank_main(args)
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -21,76 +22,99 @@
 
 namespace {
 
-// Multi-wave kernel workspace: one per (device, stream), created on first use and kept for the life
-// of the process (64 MiB on MI355X: 2 048 tables of 32 KiB).  SZ_KERNEL=single disables the dual kernel.
+// Multi-wave kernel workspace: one per (device, stream), created when a launch first has enough blocks
+// for the multi-wave kernel and kept until the stream's resources are released (64 MiB on MI355X:
+// 2 048 tables of 32 KiB).  SZ_KERNEL=single disables the dual kernel.
+// The workspace holds the launch state of ONE launch sequence at a time (sample counters, block
+// queue): `launch_mu` is held while a call enqueues its reset / sample / single / dual kernels, so
+// that two host threads launching on the same stream (e.g. both on the NULL stream) cannot
+// interleave those sequences -- on the stream the kernels of one call then run back to back.
+struct DualSlot {
+    szk::DualScratch sc{nullptr, nullptr, 0, 0, szk::kDualAuto};
+    std::mutex launch_mu;
+};
 std::mutex g_dual_mutex;
-std::map<std::pair<int, hipStream_t>, szk::DualScratch> g_dual;
+std::map<std::pair<int, hipStream_t>, std::unique_ptr<DualSlot>> g_dual;
 
-const szk::DualScratch *dual_scratch_for(hipStream_t stream)
+int kernel_mode()
 {
-    // SZ_KERNEL=single: never; SZ_KERNEL=dual: always, from two blocks up (tests); default (auto):
-    // when there are enough blocks to give every SIMD two waves, a sample of the data decides.
-    // Read on every call so that a test can switch modes inside one process.
+    // SZ_KERNEL=single: never the multi-wave kernel; SZ_KERNEL=dual: always, from two blocks up (tests);
+    // default (auto): when there are enough blocks to give every SIMD two waves, a sample of the data
+    // decides.  Read on every call so that a test can switch modes inside one process.
     const char *e = getenv("SZ_KERNEL");
-    const int mode = !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : 0;
-    thread_local szk::DualScratch view;
+    return !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : 0;
+}
+
+// The workspace slot of (current device, stream) for a launch of n_blocks, or nullptr when the
+// single kernel is to run (mode, too few blocks, no memory, stream being captured before a first use).
+// `view` receives the launch parameters for this call.
+DualSlot *dual_slot_for(hipStream_t stream, uint32_t n_blocks, szk::DualScratch *view)
+{
+    const int mode = kernel_mode();
     if (mode == 1)
         return nullptr;
-    int dev = 0;
+    int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess)
         return nullptr;
     std::lock_guard<std::mutex> lock(g_dual_mutex);
     auto key = std::make_pair(dev, stream);
-    auto finish = [&](const szk::DualScratch &sc) -> const szk::DualScratch * {
-        if (!sc.tables)
-            return nullptr;
-        view = sc;
-        view.mode = mode == 2 ? szk::kDualAlways : szk::kDualAuto;
-        view.min_blocks = mode == 2 ? 2u : 2u * sc.n_slots;
-        return &view;
-    };
     auto it = g_dual.find(key);
-    if (it != g_dual.end())
-        return finish(it->second);
-    szk::DualScratch sc{nullptr, nullptr, 0, 0, mode == 2 ? szk::kDualAlways : szk::kDualAuto};
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return nullptr;  // no allocation while a graph is being captured: single kernel this time
-    }
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
-        sc.n_slots = 4u * (uint32_t)cus;  // four workgroups per CU, kGroupWaves waves each
+    if (it == g_dual.end()) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return nullptr;
+        const uint32_t n_slots = 4u * (uint32_t)cus;  // four workgroups per CU, kGroupWaves waves each
+        const uint32_t min_blocks = mode == 2 ? 2u : 2u * n_slots;
+        if (n_blocks < min_blocks)
+            return nullptr;  // (a 130-byte sz_compress never pays for the 64 MiB workspace)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;  // no allocation while a graph is being captured: single kernel this time
+        }
+        std::unique_ptr<DualSlot> slot(new DualSlot);
+        slot->sc.n_slots = n_slots;
         void *t = nullptr, *g = nullptr;
         const size_t gbytes = 64;  // [repeats, positions, next block] of a launch
-        const size_t tbytes = (size_t)sc.n_slots * szk::kDualTablesPerGroup * szk::kDualTableBytes;
+        const size_t tbytes = (size_t)n_slots * szk::kDualTablesPerGroup * szk::kDualTableBytes;
         if (hipMalloc(&t, tbytes) == hipSuccess && hipMalloc(&g, gbytes) == hipSuccess &&
             hipMemsetAsync(t, 0, tbytes, stream) == hipSuccess &&
             hipMemsetAsync(g, 0, gbytes, stream) == hipSuccess) {
-            sc.tables = static_cast<uint16_t *>(t);  // (every wave zeroes its table again before each block)
-            sc.select = static_cast<uint32_t *>(g);
+            slot->sc.tables = static_cast<uint16_t *>(t);  // (every wave zeroes its table again before each block)
+            slot->sc.select = static_cast<uint32_t *>(g);
         } else {
             (void)hipGetLastError();
             if (t) (void)hipFree(t);
             if (g) (void)hipFree(g);
+            return nullptr;  // tried again by the next large launch
         }
+        it = g_dual.emplace(key, std::move(slot)).first;
     }
-    g_dual[key] = sc;
-    return finish(sc);
+    DualSlot *s = it->second.get();
+    *view = s->sc;
+    view->mode = mode == 2 ? szk::kDualAlways : szk::kDualAuto;
+    view->min_blocks = mode == 2 ? 2u : 2u * s->sc.n_slots;
+    if (n_blocks < view->min_blocks)
+        return nullptr;
+    return s;
 }
 
 // Frees the multi-wave workspace that belongs to a stream which is about to be destroyed.
 void drop_dual_scratch(int dev, hipStream_t stream)
 {
-    std::lock_guard<std::mutex> lock(g_dual_mutex);
-    auto it = g_dual.find(std::make_pair(dev, stream));
-    if (it == g_dual.end())
-        return;
-    if (it->second.tables)
-        (void)hipFree(it->second.tables);
-    if (it->second.select)
-        (void)hipFree(it->second.select);
-    g_dual.erase(it);
+    std::unique_ptr<DualSlot> slot;
+    {
+        std::lock_guard<std::mutex> lock(g_dual_mutex);
+        auto it = g_dual.find(std::make_pair(dev, stream));
+        if (it == g_dual.end())
+            return;
+        slot = std::move(it->second);
+        g_dual.erase(it);
+    }
+    std::lock_guard<std::mutex> launch(slot->launch_mu);  // (no launch sequence is half enqueued)
+    if (slot->sc.tables)
+        (void)hipFree(slot->sc.tables);
+    if (slot->sc.select)
+        (void)hipFree(slot->sc.select);
 }
 
 thread_local int tl_hip_error = 0;
@@ -161,7 +185,9 @@ struct Workspace {
         device = -1;
     }
 };
-thread_local Workspace tl_ws;  // deliberately not freed at thread exit (HIP may be gone by then)
+// Deliberately not freed at thread exit (HIP may be gone by then): a host thread that used the
+// host-buffer API or the RoCC surface calls sz_release_thread_resources() before it ends (snappy_hip.h).
+thread_local Workspace tl_ws;
 
 size_t put_varint32(uint8_t *dst, uint32_t v)
 {
@@ -241,9 +267,13 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
     if (const char *dbg = getenv("SZ_DEBUG_FLAGS"))
         flags |= (uint32_t)strtoul(dbg, nullptr, 0) & 0xff00u;
 #endif
+    szk::DualScratch view;
+    DualSlot *slot = dual_slot_for(static_cast<hipStream_t>(stream), n_blocks, &view);
+    std::unique_lock<std::mutex> seq;  // one launch sequence at a time per workspace
+    if (slot)
+        seq = std::unique_lock<std::mutex>(slot->launch_mu);
     SZ_HIP(szk::launch_compress_blocks(d_src, in_stride, d_in_len, n_blocks, d_dst, dst_stride, d_out_len,
-                                       flags, dual_scratch_for(static_cast<hipStream_t>(stream)),
-                                       static_cast<hipStream_t>(stream)));
+                                       flags, slot ? &view : nullptr, static_cast<hipStream_t>(stream)));
     return SZ_OK;
 }
 
@@ -257,8 +287,13 @@ int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t sl
     const size_t longest = n < SZ_BLOCK_SIZE ? n : SZ_BLOCK_SIZE;
     if (slot_stride < sz_max_compressed_length(longest) + 5)
         return SZ_ENOSPC;
-    SZ_HIP(szk::launch_compress_stream(d_src, n, d_slots, slot_stride, d_len, flags,
-                                       dual_scratch_for(static_cast<hipStream_t>(stream)),
+    const uint32_t n_blocks = (uint32_t)((n + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
+    szk::DualScratch view;
+    DualSlot *slot = dual_slot_for(static_cast<hipStream_t>(stream), n_blocks, &view);
+    std::unique_lock<std::mutex> seq;  // one launch sequence at a time per workspace
+    if (slot)
+        seq = std::unique_lock<std::mutex>(slot->launch_mu);
+    SZ_HIP(szk::launch_compress_stream(d_src, n, d_slots, slot_stride, d_len, flags, slot ? &view : nullptr,
                                        static_cast<hipStream_t>(stream)));
     return SZ_OK;
 }
@@ -415,7 +450,7 @@ int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *
     Workspace &ws = tl_ws;
     if ((rc = ws.ensure_stream()))
         return rc;
-    if ((rc = ws.reserve(0, n)) || (rc = ws.reserve(1, ulen + 16)) || (rc = ws.reserve(2, 16)))
+    if ((rc = ws.reserve(0, n + 8)) || (rc = ws.reserve(1, ulen + 16)) || (rc = ws.reserve(2, 16)))  // (the stream index reads up to n + 8)
         return rc;
     uint8_t *d_in = static_cast<uint8_t *>(ws.buf[0]);
     uint8_t *d_out = static_cast<uint8_t *>(ws.buf[1]);

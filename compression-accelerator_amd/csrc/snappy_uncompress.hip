@@ -188,8 +188,8 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
     while (st == 0 && ip < n) {
         // tag + up to 4 trailing bytes in one go when they are in bounds
         uint32_t tag, extra = 0;
-        if (ip + 5 <= n) {
-            const uint64_t x = ld64(in + ip) ;
+        if (ip + 8 <= n) {  // (the 8-byte load stays inside the stream: no padding is asked of the caller)
+            const uint64_t x = ld64(in + ip);
             tag = uni((uint32_t)x & 0xff);
             extra = uni((uint32_t)(x >> 8));
         } else {

@@ -16,13 +16,26 @@ def shard_range(n_blocks_total, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def gather_lengths(local_lens, n_blocks_total=None, group=None, out=None, offsets=None):
+def check_lengths(lens, slot_stride=None):
+    """Raises if a per-block length is one of the kernels' error markers (0xffffffff: block longer than
+    64 KiB; 0xfffffffe: poisoned result), which read as negative int32, or exceeds the slot stride.
+    One device synchronisation: call it where the lengths are consumed, not inside a timed loop."""
+    bad = lens < 0
+    if slot_stride is not None:
+        bad = bad | (lens > slot_stride)
+    if bool(bad.any().item()):
+        first = int(torch.nonzero(bad)[0].item())
+        raise ValueError("block %d came back with the error marker / length %d" % (first, int(lens[first].item())))
+
+
+def gather_lengths(local_lens, n_blocks_total=None, group=None, out=None, offsets=None, check=False):
     """all_gather of per-block lengths.  local_lens: int32 tensor [blocks of this rank] (CUDA for
     nccl, CPU for gloo).  Returns (all_lens int32[n_total], offsets int64[n_total+1]) where
     offsets is the exclusive prefix sum = position of every block in the packed global stream.
     Ranks may hold different block counts (shard_range); shorter ones are padded for the collective.
     `out` / `offsets`: optional preallocated results (a steady-state caller passes them so that a
-    step is one collective and one scan, with no allocation)."""
+    step is one collective and one scan, with no allocation).  `check`: raise on error markers in the
+    gathered lengths (check_lengths: synchronises) instead of returning offsets computed from them."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         all_lens = local_lens
         if out is not None:
@@ -51,6 +64,8 @@ def gather_lengths(local_lens, n_blocks_total=None, group=None, out=None, offset
             if out is not None:
                 out.copy_(all_lens)
                 all_lens = out
+    if check:
+        check_lengths(all_lens)
     if offsets is None:
         offsets = torch.zeros(all_lens.numel() + 1, dtype=torch.int64, device=all_lens.device)
     else:

@@ -161,11 +161,16 @@ uint64_t rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2);
 int sz_rocc_last_error(void);
 
 /* ---- misc ------------------------------------------------------------------------------- */
-/* Frees the calling thread's cached device workspace (used by the host-buffer API). */
+/* Frees the calling thread's cached device workspace (its stream, five buffers and the 64 MiB below),
+ * used by the host-buffer API and the RoCC surface.  It is NOT freed when the thread exits (the HIP
+ * runtime may be gone by then): a thread pool that retires threads calls this in each of them first. */
 void sz_release_thread_resources(void);
 /* Frees the 64 MiB workspace the compress entry points keep for `stream` on the current device
- * (waits for the stream first).  Call it before destroying a stream that was used for compression
- * if the process creates many; the next compress call on the stream allocates a new one. */
+ * (waits for the stream first).  The workspace is created by the first launch on the stream that
+ * has enough blocks for the multi-wave kernel (8 x CUs), never by small calls.  Call this before
+ * destroying a stream that was used for compression if the process creates many; the next large
+ * compress call on the stream allocates a new one.  Host threads may launch on one stream at the
+ * same time: the launch sequence of each call is enqueued as a unit. */
 int sz_release_stream_resources(void *stream);
 int sz_device_count(void);            /* number of visible GPUs (0 if none / no driver) */
 int sz_last_hip_error(void);          /* last hipError_t seen by this thread */

@@ -33,11 +33,14 @@
  *      tests/golden/make_golden.py (committed).  The reference itself pins no
  *      output bytes (its tests only print), so byte-level parity rests on those.
  */
+#define _GNU_SOURCE /* sched_getaffinity, pthread_setaffinity_np (timed batch driver) */
 #include "snappy_oracle.h"
 
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------ utils */
 
@@ -182,8 +185,21 @@ size_t oracle_compress_fragment(const uint8_t *in, size_t n, uint8_t *dst)
             for (;;) {
                 size_t base = ip;
                 size_t m = 4;
+                /* FindMatchLength: 8 bytes at a time while 8 are left, then bytewise (same count
+                 * as a pure byte loop; compares on up to the end of the fragment) */
+                while (ip + m + 8 <= n) {
+                    uint64_t x, y;
+                    memcpy(&x, in + cand + m, 8);
+                    memcpy(&y, in + ip + m, 8);
+                    if (x != y) {
+                        m += (size_t)(__builtin_ctzll(x ^ y) >> 3);
+                        goto matched;
+                    }
+                    m += 8;
+                }
                 while (ip + m < n && in[cand + m] == in[ip + m])
                     m++;
+            matched:
                 ip += m;
                 op = emit_copy(op, (uint32_t)(base - cand), (uint32_t)m);
                 next_emit = ip;
@@ -351,6 +367,90 @@ int oracle_compress_blocks(const uint8_t *src, size_t in_stride, const uint32_t 
     job_main(&jobs[0]);
     for (int t = 1; t < n_threads; t++)
         pthread_join(tids[t], NULL);
+    free(jobs);
+    free(tids);
+    return 0;
+}
+
+/* ------------------------------------------------------- timed batch driver
+ * The CPU baseline of bench.py (the reference's own
+ * measurement loop is workloads/snappy/overlay/root/compress.cc:26-34: 20
+ * repetitions, averaged).  Threads are created ONCE and pinned to distinct
+ * CPUs of the process's affinity set, every buffer is the caller's and is
+ * reused by every repetition, the repetitions are separated by a barrier, and
+ * the clock runs around all of them: nothing is allocated or spawned inside the
+ * timed region. */
+struct tjob {
+    struct job j;
+    int reps, cpu;
+    pthread_barrier_t *bar;
+    double *seconds;
+    int leader;
+};
+
+static void *tjob_main(void *arg)
+{
+    struct tjob *t = (struct tjob *)arg;
+    if (t->cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(t->cpu, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    job_main(&t->j); /* warm-up pass: page in the output, warm the caches */
+    pthread_barrier_wait(t->bar);
+    struct timespec t0, t1;
+    if (t->leader)
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 0; r < t->reps; r++) {
+        job_main(&t->j);
+        pthread_barrier_wait(t->bar);
+    }
+    if (t->leader) {
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        *t->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    }
+    return NULL;
+}
+
+int oracle_time_compress_blocks(const uint8_t *src, size_t in_stride, uint32_t n_blocks, uint8_t *dst,
+                                size_t dst_stride, uint32_t *out_len, int per_block_varint,
+                                int n_threads, int reps, double *seconds)
+{
+    if (n_threads < 1 || reps < 1 || !seconds || in_stride > ORACLE_BLOCK || n_blocks < (uint32_t)n_threads)
+        return -1;
+    cpu_set_t allowed;
+    int cpus[1024], n_cpus = 0;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+        for (int c = 0; c < 1024 && n_cpus < 1024; c++)
+            if (CPU_ISSET(c, &allowed))
+                cpus[n_cpus++] = c;
+    struct tjob *jobs = (struct tjob *)calloc((size_t)n_threads, sizeof(*jobs));
+    pthread_t *tids = (pthread_t *)calloc((size_t)n_threads, sizeof(*tids));
+    pthread_barrier_t bar;
+    if (!jobs || !tids || pthread_barrier_init(&bar, NULL, (unsigned)n_threads) != 0) {
+        free(jobs);
+        free(tids);
+        return -2;
+    }
+    *seconds = 0.0;
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].j = (struct job){src, in_stride, NULL, dst, dst_stride, out_len, per_block_varint,
+                                 (uint32_t)((uint64_t)n_blocks * t / n_threads),
+                                 (uint32_t)((uint64_t)n_blocks * (t + 1) / n_threads)};
+        jobs[t].reps = reps;
+        jobs[t].cpu = n_cpus >= n_threads ? cpus[t] : -1;
+        jobs[t].bar = &bar;
+        jobs[t].seconds = seconds;
+        jobs[t].leader = t == 0;
+        if (t > 0)
+            pthread_create(&tids[t], NULL, tjob_main, &jobs[t]);
+    }
+    /* the leader runs on a thread of its own too, so that pinning never touches the caller */
+    pthread_create(&tids[0], NULL, tjob_main, &jobs[0]);
+    for (int t = 0; t < n_threads; t++)
+        pthread_join(tids[t], NULL);
+    pthread_barrier_destroy(&bar);
     free(jobs);
     free(tids);
     return 0;

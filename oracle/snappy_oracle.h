@@ -46,6 +46,14 @@ int oracle_compress_blocks(const uint8_t *src, size_t in_stride, const uint32_t 
                            uint32_t n_blocks, uint8_t *dst, size_t dst_stride,
                            uint32_t *out_len, int per_block_varint, int n_threads);
 
+/* Timed form for the CPU baseline: n_threads pinned pthreads created once, one
+ * untimed warm-up pass, then `reps` timed passes over the same caller-owned
+ * buffers (barrier between passes); *seconds = wall time of the timed passes.
+ * Fixed-size blocks only. */
+int oracle_time_compress_blocks(const uint8_t *src, size_t in_stride, uint32_t n_blocks, uint8_t *dst,
+                                size_t dst_stride, uint32_t *out_len, int per_block_varint,
+                                int n_threads, int reps, double *seconds);
+
 /* FNV-1a 64 (offset basis 1469598103934665603, prime 1099511628211). */
 uint64_t oracle_fnv1a64(const uint8_t *p, size_t n);
 

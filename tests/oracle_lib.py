@@ -43,6 +43,9 @@ def lib():
     L.oracle_compress_blocks.argtypes = [u8p, ctypes.c_size_t, u8p, ctypes.c_uint32, u8p, ctypes.c_size_t,
                                          u8p, ctypes.c_int, ctypes.c_int]
     L.oracle_compress_blocks.restype = ctypes.c_int
+    L.oracle_time_compress_blocks.argtypes = [u8p, ctypes.c_size_t, ctypes.c_uint32, u8p, ctypes.c_size_t, u8p,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    L.oracle_time_compress_blocks.restype = ctypes.c_int
     L.oracle_fnv1a64.argtypes = [u8p, ctypes.c_size_t]
     L.oracle_fnv1a64.restype = ctypes.c_uint64
     _lib = L
@@ -104,6 +107,22 @@ def compress_blocks(src, in_stride, n_blocks, in_len=None, dst_stride=None, per_
     if rc != 0:
         raise RuntimeError("oracle_compress_blocks rc=%d" % rc)
     return dst, out_len
+
+
+def time_compress_blocks(src, in_stride, n_blocks, threads, reps, per_block_varint=True):
+    """Seconds for `reps` passes of the oracle over n_blocks fixed-size blocks on `threads` pinned
+    pthreads (buffers allocated here, outside the timed region; one warm-up pass).  CPU baseline."""
+    a = _as_u8(src)
+    dst_stride = max_compressed_length(in_stride) + 6
+    dst = np.empty((n_blocks, dst_stride), dtype=np.uint8)
+    out_len = np.zeros(n_blocks, dtype=np.uint32)
+    sec = ctypes.c_double(0.0)
+    rc = lib().oracle_time_compress_blocks(a.ctypes.data, in_stride, n_blocks, dst.ctypes.data, dst_stride,
+                                           out_len.ctypes.data, 1 if per_block_varint else 0, threads, reps,
+                                           ctypes.byref(sec))
+    if rc != 0:
+        raise RuntimeError("oracle_time_compress_blocks rc=%d" % rc)
+    return sec.value, out_len
 
 
 def fnv1a64(data):

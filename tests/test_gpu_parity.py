@@ -185,3 +185,24 @@ def test_fixed_size_small_blocks_have_their_own_kernel():
         out = dst.reshape(nb, stride).cpu().numpy()
         for i in range(nb):
             _assert_same(out[i, :ln[i]].tobytes(), oracle_lib.raw_compress(blocks[i]), "bs=%d block %d" % (bs, i))
+
+
+def test_ten_thousand_small_blocks_every_one_against_the_oracle():
+    """>= 10 000 fixed small blocks (4 KiB and 1 KiB pages of text, and of the c3/text/c5 mix) in one
+    launch each, every block compared with the oracle."""
+    import sys
+    import torch
+    import build_util
+    import parity_util
+    sys.path.insert(0, build_util.ROOT)
+    import bench
+    P = pkg()
+    dev = torch.device("cuda:0")
+    for kind, bs, n64 in (("text", 4096, 1024), ("mix", 4096, 768), ("text", 1024, 192)):
+        src = bench.make_input(kind, 0, n64, dev)  # n64 x 64 KiB, cut into pages
+        nb = n64 * 65536 // bs
+        assert nb >= 10000
+        stride = (int(P.max_compressed_length(bs)) + 8 + 15) // 16 * 16
+        dst, ol = P.compress_blocks(src, bs, nb, dst_stride=stride)
+        torch.cuda.synchronize()
+        parity_util.assert_all_blocks_match_oracle(src, dst, ol, nb, stride, what="%s pages of %d" % (kind, bs), block=bs)

@@ -88,3 +88,45 @@ def test_single_process_gather_is_identity():
     lens = torch.tensor([5, 7, 11], dtype=torch.int32)
     a, o = sharding.gather_lengths(lens)
     assert a.tolist() == [5, 7, 11] and o.tolist() == [0, 5, 12, 23]
+    a, o = sharding.gather_lengths(lens, check=True)
+    assert o.tolist() == [0, 5, 12, 23]
+
+
+def test_error_markers_in_lengths_are_reported_not_summed():
+    """The kernels flag a rejected / poisoned block with 0xffffffff / 0xfffffffe in out_len, which the
+    int32 tensors of the binding show as -1 / -2: offsets computed over them would be silently wrong."""
+    load_package()
+    from compression_accelerator_amd import sharding
+    lens = torch.tensor([5, -1, 11], dtype=torch.int32)
+    with pytest.raises(ValueError):
+        sharding.gather_lengths(lens, check=True)
+    with pytest.raises(ValueError):
+        sharding.check_lengths(torch.tensor([5, 7, 80000], dtype=torch.int32), slot_stride=76544)
+    sharding.check_lengths(torch.tensor([5, 7, 76544], dtype=torch.int32), slot_stride=76544)
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """bench.py --gpus N without torchrun: bench.launch_ranks starts N ranks as a child process
+    (python -m torch.distributed.run ...), relays rank 0's JSON line and the exit code.  Rehearsed
+    here with two gloo ranks whose lengths come from the oracle (tests/bench_rank_stub.py)."""
+    import json
+    import bench
+    stub = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_rank_stub.py")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    rc, line, out, err = bench.launch_ranks(2, stub, ["5"], env=env, timeout=300)
+    assert rc == 0, err[-2000:]
+    assert line is not None, out[-2000:]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["rccl_ranks_seen"] == 2 and r["gathered_layout_ok"] is True
+    want = [len(oracle_lib.raw_compress(x)) for x in _blocks(10)]
+    assert r["lens"] == want and r["total"] == sum(want)
+    # a failing rank is reported through the exit code, not swallowed
+    rc2, line2, _, _ = bench.launch_ranks(2, stub, ["not-a-number"], env=env, timeout=300)
+    assert rc2 != 0 and line2 is None
+
+
+def test_bench_arguments_default_to_one_gpu_and_short_runs():
+    import bench
+    a = bench.parse_args([])
+    assert (a.gpus, a.steps, a.warmup, a.workload, a.blocks_per_gpu) == (1, 20, 3, "c3", 32768)
