@@ -30,7 +30,7 @@ namespace {
 // that two host threads launching on the same stream (e.g. both on the NULL stream) cannot
 // interleave those sequences -- on the stream the kernels of one call then run back to back.
 struct DualSlot {
-    szk::DualScratch sc{nullptr, nullptr, 0, 0, szk::kDualAuto};
+    szk::DualScratch sc{nullptr, nullptr, nullptr, 0, 0, 0, szk::kDualAuto};
     std::mutex launch_mu;
 };
 std::mutex g_dual_mutex;
@@ -40,9 +40,10 @@ int kernel_mode()
 {
     // SZ_KERNEL=single: never the multi-wave kernel; SZ_KERNEL=dual: always, from two blocks up (tests);
     // default (auto): when there are enough blocks to give every SIMD two waves, a sample of the data
-    // decides.  Read on every call so that a test can switch modes inside one process.
+    // decides; SZ_KERNEL=route: per block inside the launch (the single kernel hands compressible blocks
+    // over).  Read on every call so that a test can switch modes inside one process.
     const char *e = getenv("SZ_KERNEL");
-    return !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : 0;
+    return !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : strcmp(e, "route") == 0 ? 3 : 0;
 }
 
 // The workspace slot of (current device, stream) for a launch of n_blocks, or nullptr when the
@@ -73,25 +74,29 @@ DualSlot *dual_slot_for(hipStream_t stream, uint32_t n_blocks, szk::DualScratch 
         }
         std::unique_ptr<DualSlot> slot(new DualSlot);
         slot->sc.n_slots = n_slots;
-        void *t = nullptr, *g = nullptr;
-        const size_t gbytes = 64;  // [repeats, positions, next block] of a launch
+        void *t = nullptr, *g = nullptr, *q = nullptr;
+        const size_t gbytes = 64;  // launch state
         const size_t tbytes = (size_t)n_slots * szk::kDualTablesPerGroup * szk::kDualTableBytes;
+        const size_t qbytes = (size_t)szk::kDualQueueEntries * sizeof(uint32_t);
         if (hipMalloc(&t, tbytes) == hipSuccess && hipMalloc(&g, gbytes) == hipSuccess &&
-            hipMemsetAsync(t, 0, tbytes, stream) == hipSuccess &&
+            hipMalloc(&q, qbytes) == hipSuccess && hipMemsetAsync(t, 0, tbytes, stream) == hipSuccess &&
             hipMemsetAsync(g, 0, gbytes, stream) == hipSuccess) {
             slot->sc.tables = static_cast<uint16_t *>(t);  // (every wave zeroes its table again before each block)
             slot->sc.select = static_cast<uint32_t *>(g);
+            slot->sc.queue = static_cast<uint32_t *>(q);
+            slot->sc.queue_cap = szk::kDualQueueEntries;
         } else {
             (void)hipGetLastError();
             if (t) (void)hipFree(t);
             if (g) (void)hipFree(g);
+            if (q) (void)hipFree(q);
             return nullptr;  // tried again by the next large launch
         }
         it = g_dual.emplace(key, std::move(slot)).first;
     }
     DualSlot *s = it->second.get();
     *view = s->sc;
-    view->mode = mode == 2 ? szk::kDualAlways : szk::kDualAuto;
+    view->mode = mode == 2 ? szk::kDualAlways : mode == 3 ? szk::kDualRoute : szk::kDualAuto;
     view->min_blocks = mode == 2 ? 2u : 2u * s->sc.n_slots;
     if (n_blocks < view->min_blocks)
         return nullptr;
@@ -115,6 +120,8 @@ void drop_dual_scratch(int dev, hipStream_t stream)
         (void)hipFree(slot->sc.tables);
     if (slot->sc.select)
         (void)hipFree(slot->sc.select);
+    if (slot->sc.queue)
+        (void)hipFree(slot->sc.queue);
 }
 
 thread_local int tl_hip_error = 0;

@@ -352,7 +352,11 @@ struct HashTab {
 };
 
 // One block by one wavefront.  kChunks = 1 KiB chunks of the block kept in registers.
-template <int kBlkChunks, bool kLean, typename Tab>
+// Auto mode routes blocks between the two kernels: the single kernel (kRoute) gives a block up as
+// soon as it has emitted its first copy and marks it for the multi-wave kernel.
+static constexpr uint32_t kRoutedMarker = 0xfffffffdu;  // in out_len[b]: "compressible, not done yet"
+
+template <int kBlkChunks, bool kLean, typename Tab, bool kRoute = false>
 __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uint8_t *__restrict__ in,
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
                                                        uint32_t lane)
@@ -543,6 +547,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             op = uni(op); kcur = uni(kcur); trips = uni(trips); poisoned = unib(poisoned); hold_fast = unib(hold_fast);
             prepW = uni(prepW); prepC = unib(prepC); prepped = unib(prepped); first_scan = unib(first_scan);
             big_len = uni(big_len);
+            if (kRoute && chain)  // the first copy of this block: compressible data, the multi-wave kernel takes it
+                return kRoutedMarker;
             if (poisoned || ++trips > 2u * kMaxBlock) {
                 poisoned = true;
                 break;
@@ -1361,22 +1367,36 @@ __device__ __forceinline__ uint32_t block_length(const uint32_t *__restrict__ in
     return uni(n_raw);
 }
 
-// ---- kernel selection by sampled compressibility (auto mode)
+// ---- choosing between the two kernels: per launch by a sample (auto, the default) or per block (route)
 // The multi-wave ("dual") kernel wins on compressible data (three waves per SIMD fill each other's
 // issue slots: text +65%, low-entropy +67%), the single kernel on incompressible data (whole block in
-// registers, no slow global-table wave: +7%).  A tiny sampling kernel looks at the first 1 KiB of up
-// to 64 evenly spaced blocks and counts 4-byte shingles seen before (16-bit hash into an LDS
-// bitmap); both kernels are launched and the one not chosen exits at once.  Either kernel produces
-// the same bytes, so a wrong guess only costs speed.
+// registers, no slow global-table wave: +7%).  AUTO: a tiny sampling kernel decides for the whole launch
+// (below).  ROUTE (SZ_KERNEL=route): one launch may hold both kinds, so the choice is made per block,
+// inside the launch: the single kernel starts every block,
+// and the first copy it is about to follow up (chain state: the data does repeat) makes it give the
+// block up -- out_len[b] = kRoutedMarker -- at a cost of a few microseconds; the multi-wave kernel,
+// next on the stream, compresses exactly the marked blocks from scratch.  Incompressible blocks never
+// reach a copy and stay where the register-resident stream is.  No host synchronisation, no sampling
+// pass: the call stays asynchronous and graph-capturable; either kernel produces the same bytes, so
+// the routing only decides speed.  Measured (gpurun_out/r2i, 2026-10): against AUTO, ROUTE costs the
+// blocks it hands over their first microseconds and a wasted 64 KiB register stream each (c5 675 -> 564
+// GB/s, text -1 %), and an all-incompressible launch two more launches (c3 -3 %); on BASELINE.json's C4
+// mix (equal thirds) it gains nothing (141 vs 143 GB/s) because the incompressible third costs the
+// multi-wave kernel only 2 % of the launch -- what holds the mix under the harmonic mean of its parts
+// at 16 386 blocks is the tail of the persistent grid (155 GB/s at 65 536 blocks either way).  ROUTE
+// pays when a launch is mostly incompressible with a compressible minority, which AUTO sends through
+// the single kernel whole.  Hence opt-in.
+__global__ __launch_bounds__(64) void reset_launch_state_kernel(uint32_t *__restrict__ select)
+{
+    if (threadIdx.x < 4)
+        select[threadIdx.x] = 0;
+}
+
+// Sampled choice (default auto mode): repeats among the 4-byte shingles of the first 1 KiB of up to 64
+// evenly spaced blocks; both kernels are launched and the one not chosen exits at once.
 __device__ __forceinline__ bool prefers_dual(const uint32_t *__restrict__ select)
 {
     return (uint64_t)select[0] * 10 > select[1];  // repeats > 10 % of the sampled positions
-}
-
-__global__ __launch_bounds__(64) void reset_launch_state_kernel(uint32_t *__restrict__ select)
-{
-    if (threadIdx.x < 3)
-        select[threadIdx.x] = 0;
 }
 
 __global__ __launch_bounds__(256) void sample_compressibility_kernel(
@@ -1410,11 +1430,31 @@ __global__ __launch_bounds__(256) void sample_compressibility_kernel(
     }
 }
 
+
+// Between the two kernels (SZ_KERNEL=route): the blocks the single kernel marked, as a compact queue for the
+// multi-wave kernel's waves.  One ballot and one atomic add per wave of 64 blocks (the order of the
+// queue does not matter); select[3] = number of routed blocks.
+__global__ __launch_bounds__(256) void compact_routed_kernel(const uint32_t *__restrict__ out_len, uint32_t n_blocks,
+                                                            uint32_t *__restrict__ queue, uint32_t *__restrict__ select)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool routed = i < n_blocks && out_len[i] == kRoutedMarker;
+    const uint64_t m = ballot64(routed);
+    if (m == 0)
+        return;
+    uint32_t base = 0;
+    if (lane == 0)
+        base = atomicAdd(&select[3], (uint32_t)__builtin_popcountll(m));
+    base = uni(base);
+    if (routed)
+        queue[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1))] = i;
+}
+
 // Single kernel: one 64-lane workgroup per block, table in LDS, whole block in registers.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void compress_blocks_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
-    uint32_t *__restrict__ out_len, uint32_t flags, const uint32_t *__restrict__ select)
+    uint32_t *__restrict__ out_len, uint32_t flags, uint32_t route, const uint32_t *__restrict__ select)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];  // the whole LDS budget: 32 KiB
     const uint32_t lane = threadIdx.x;
@@ -1429,8 +1469,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         return;
     }
     const HashTab<true> tab{lds_tab, nullptr, nullptr};
-    const uint32_t op = compress_one_block<64, false>(tab, src + (uint64_t)b * in_stride, n,
-                                               dst + (uint64_t)b * dst_stride, flags, lane);
+    uint32_t op;
+    if (route)  // auto mode: compressible blocks are left to the multi-wave kernel (kRoutedMarker)
+        op = compress_one_block<64, false, HashTab<true>, true>(tab, src + (uint64_t)b * in_stride, n,
+                                                                 dst + (uint64_t)b * dst_stride, flags, lane);
+    else
+        op = compress_one_block<64, false>(tab, src + (uint64_t)b * in_stride, n, dst + (uint64_t)b * dst_stride,
+                                           flags, lane);
     out_len[b] = op;  // (a9) every lane, same address, same value
 }
 
@@ -1453,11 +1498,16 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
     uint32_t *__restrict__ out_len, uint32_t flags, uint16_t *scratch_tables,
-    uint32_t *__restrict__ select, uint32_t auto_mode)
+    uint32_t *__restrict__ select, const uint32_t *__restrict__ queue, uint32_t auto_mode)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
     __shared__ uint32_t dup_bm[(kGroupWaves - 1) * 512];  // one 16384-bit bitmap per global-table wave
     if (auto_mode && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
+        return;
+    // route mode (queue != nullptr): the blocks of this launch's queue, filled behind the single kernel
+    // (an all-incompressible launch leaves it empty: every workgroup is gone before it does anything)
+    const uint32_t n_work = queue ? uni(select[3]) : n_blocks;
+    if (blockIdx.x * kGroupWaves >= n_work)
         return;
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1480,8 +1530,10 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
             b = atomicAdd(reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)qhi << 32) | qlo)), 1u);
         }
         b = uni(b);
-        if (b >= n_blocks)
+        if (b >= n_work)
             break;
+        if (queue)
+            b = uni(queue[b]);
         const uint32_t n = block_length(in_len, total_len, in_stride, b);
         if (n > kMaxBlock) {
             out_len[b] = 0xffffffffu;
@@ -1545,27 +1597,33 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
         return hipGetLastError();
     }
     const bool dual_ok = dual && dual->tables && n_blocks >= dual->min_blocks;
-    const uint32_t *select = nullptr;
-    if (dual_ok)  // [repeats, positions, next block] of this launch := 0.  (A kernel, not hipMemsetAsync:
-                  // captured into a hipGraph, the memset node made every replay after the first a no-op.)
+    const bool route = dual_ok && dual->mode == kDualRoute && dual->queue && n_blocks <= dual->queue_cap;
+    const bool sampled = dual_ok && dual->mode == kDualAuto;
+    if (dual_ok)  // launch state := 0.  (A kernel, not hipMemsetAsync: captured into a hipGraph, the
+                  // memset node made every replay after the first a no-op.)
         hipLaunchKernelGGL(reset_launch_state_kernel, dim3(1), dim3(64), 0, stream, dual->select);
-    if (dual_ok && dual->mode == kDualAuto) {
+    if (sampled) {
         // sample -> both kernels, each checks the verdict first (graph-capture safe: no host sync)
         const uint32_t ns = n_blocks < 64 ? n_blocks : 64;
         hipLaunchKernelGGL(sample_compressibility_kernel, dim3(ns), dim3(256), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dual->select);
-        select = dual->select;
     }
-    if (!dual_ok || dual->mode == kDualAuto)
+    // route mode: the single kernel starts every block and leaves the compressible ones, marked in
+    // out_len, to the multi-wave kernel behind it on the stream (no host sync either)
+    if (!dual_ok || sampled || route)
         hipLaunchKernelGGL(compress_blocks_kernel, dim3(n_blocks), dim3(64), 0, stream, src, in_stride, d_in_len,
-                           total_len, n_blocks, dst, dst_stride, d_out_len, flags, select);
+                           total_len, n_blocks, dst, dst_stride, d_out_len, flags, route ? 1u : 0u,
+                           sampled ? dual->select : (const uint32_t *)nullptr);
+    if (route)
+        hipLaunchKernelGGL(compact_routed_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, d_out_len, n_blocks,
+                           dual->queue, dual->select);
     if (dual_ok) {
         // enough blocks to keep kGroupWaves waves per SIMD busy on every CU: persistent grid
         uint32_t grid = (n_blocks + kGroupWaves - 1) / kGroupWaves;
         grid = grid < dual->n_slots ? grid : dual->n_slots;
         hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(64 * kGroupWaves), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->tables,
-                           dual->select, dual->mode == kDualAuto ? 1u : 0u);
+                           dual->select, route ? dual->queue : (const uint32_t *)nullptr, sampled ? 1u : 0u);
     }
     return hipGetLastError();
 }

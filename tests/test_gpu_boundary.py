@@ -242,13 +242,43 @@ def _full_size_round_trip(kind, n_blocks, expect_len=None):
     return lens
 
 
-@pytest.mark.parametrize("mode", ["single", "dual"])
+@pytest.mark.parametrize("mode", ["single", "dual", "route"])
 def test_full_size_forced_kernels(mode, monkeypatch):
-    """The two compress kernels at full size on every workload (auto mode picks one per launch)."""
+    """The two compress kernels at full size on every workload (auto mode picks one per launch), and
+    the per-block routing between them inside one launch (route: the mix holds both classes)."""
     monkeypatch.setenv("SZ_KERNEL", mode)
     _full_size_round_trip("c3", 4096, expect_len=65542)
     _full_size_round_trip("text", 2048)
     _full_size_round_trip("mix", 3072)
+
+
+def test_routing_a_compressible_minority_inside_an_incompressible_launch(monkeypatch):
+    """SZ_KERNEL=route: 4 096 incompressible blocks with every 16th replaced by text or a low-entropy
+    block (and two empty-ish ones): the single kernel keeps the former, the multi-wave kernel gets
+    the latter through the queue; every block equals the oracle and decodes."""
+    import sys
+    import torch
+    sys.path.insert(0, build_util.ROOT)
+    import bench
+    monkeypatch.setenv("SZ_KERNEL", "route")
+    P = pkg()
+    dev = torch.device("cuda:0")
+    nb = 4096
+    src = bench.make_input("c3", 0, nb, dev).reshape(nb, 65536).clone()
+    text = bench.make_input("text", 5, nb // 16, dev).reshape(-1, 65536)
+    c5 = bench.make_input("c5", 9, nb // 32, dev).reshape(-1, 65536)
+    src[0::16] = text
+    src[8::32] = c5
+    src[3] = 0            # one long run
+    src[5, 100:] = 7
+    src = src.reshape(-1).contiguous()
+    dst, out_len = P.compress_blocks(src, 65536, nb)
+    back, ulen, status = P.uncompress_blocks(dst, P.SLOT_STRIDE, out_len, nb)
+    torch.cuda.synchronize()
+    assert int(status.abs().sum().item()) == 0 and torch.equal(back, src)
+    lens = out_len.cpu().numpy()
+    assert (lens[1::16] == 65542).all() and (lens[0::16] < 40000).all()
+    parity_util.assert_all_blocks_match_oracle(src, dst, out_len, nb, P.SLOT_STRIDE, what="routed launch")
 
 
 def test_global_tables_are_clean_for_every_block(monkeypatch):
