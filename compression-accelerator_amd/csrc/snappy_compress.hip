@@ -1101,6 +1101,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
                             w = tab.get(h);
                         }
+                        UNIFORM_JOIN();
                         L = __ballot(ins_lane && w != (pos & 0xffffu));
                         PROF_LAPV(9);
                         if (L == 0)
@@ -1110,6 +1111,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         asm volatile("" ::: "memory");
                         if (ins_lane)
                             tab.put(h, cand);
+                        UNIFORM_JOIN();
                     } else {
                         // Table in global memory: a read-back would be 64 more L2 misses on the critical
                         // path.  Shared buckets are found in a 16384-bit LDS bitmap instead (atomic OR:

@@ -134,3 +134,39 @@ def test_no_reloaded_spill_feeds_a_memory_instruction_scalar_base(tmp_path):
                     offenders.append("%s: %s  <-  %s" % (name, l.strip(), lines[j].strip()))
                     break
     assert not offenders, "\n".join(offenders)
+
+
+def test_parse_state_of_the_compress_kernels_is_provably_wave_uniform(tmp_path):
+    """The compress kernels keep their parse state (positions, masks, flags) in scalar registers only
+    while the compiler can PROVE it wave-uniform; one join of a per-lane branch merged with a uniform
+    one, or one loop left through a per-lane branch, and LLVM moves the whole state into vector
+    registers (64-bit vector arithmetic for the masks, readfirstlane round trips).
+    LLVM's own uniformity analysis is the judge here: no loop of the compress kernels other than the
+    small per-lane copy loops may have a divergent exit, and none of the parse-state variables may be
+    divergent inside the main loops."""
+    opt = "/opt/rocm/lib/llvm/bin/opt"
+    if not os.path.exists(opt):
+        pytest.skip("no opt in this image")
+    src = os.path.join(build_util.ROOT, "compression-accelerator_amd", "csrc", "snappy_compress.hip")
+    ll = os.path.join(str(tmp_path), "sc.ll")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-discard-value-names",
+                           "-I" + os.path.join(build_util.ROOT, "include"), "-I" + os.path.dirname(src),
+                           "-S", "-emit-llvm", "--cuda-device-only", src, "-o", ll], stderr=subprocess.DEVNULL)
+    r = subprocess.run([opt, "-passes=print<uniformity>", "-disable-output", ll], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = r.stderr
+    per_lane_loops = re.compile(r"entries\((for\.body|vector\.body|while\.cond\.i|for\.cond\.i\.i|for\.body53)")
+    state = re.compile(r"DIVERGENT:\s+%(P|chain|sc|scan_base|e|t|S|jj|lim|P2|chain2|sc2|Hraw|Vacc|Hpacc|V|Hp|C|kcur|trips|c_in|sc_in)"
+                       r"\.[0-9][\w.]* = ")
+    seen = 0
+    for fn in text.split("UniformityInfo for function ")[1:]:
+        name = fn.split("'")[1]
+        if "compress_blocks" not in name and "compress_small" not in name:
+            continue
+        seen += 1
+        cyc = fn.split("CYCLES WITH DIVERGENT EXIT:")[1].split("\n\n")[0] if "CYCLES WITH DIVERGENT EXIT:" in fn else ""
+        bad = [l.strip()[:100] for l in cyc.splitlines() if "entries(" in l and not per_lane_loops.search(l)]
+        assert not bad, "%s: loops left through a per-lane branch:\n%s" % (name, "\n".join(bad))
+        div = [l.strip()[:120] for l in fn.splitlines() if state.search(l)]
+        assert not div, "%s: parse state the compiler cannot prove uniform:\n%s" % (name, "\n".join(div[:10]))
+    assert seen == 3
