@@ -10,9 +10,10 @@
 //      every lane decodes "its" tag, pointer jumping (ds_bpermute) turns that into "where does a
 //      chain entering the window at lane l leave it, and how many bytes did it produce", and each
 //      hypothetical parse takes one such step.  Result per segment: 64 x (exit position, bytes).
-//   2. one wave follows the true parse segment by segment through those maps (after a literal that
-//      reaches far into a segment it parses that segment's rest itself) and notes where the true
-//      parse enters every segment and with how many bytes produced.
+//   2. the maps of 64 consecutive segments are composed into chunk maps (in parallel), one wave follows
+//      the true parse from chunk to chunk, and the chunks' segments get their entries in parallel again
+//      (details at the kernels: a chunk that the parse enters far from a segment's start is walked by
+//      that one wave, runs of equal-sized elements 64 at a time).
 //   3. one wave per segment walks its elements from that entry and records the compressed offset of
 //      every element that starts on a 64 KiB output boundary; an element that straddles a boundary
 //      means the stream was not produced fragment by fragment: the caller then decodes serially.
@@ -104,9 +105,15 @@ __device__ __forceinline__ void window_map(const uint8_t *__restrict__ in, uint3
 }
 
 // ---- 1. segment maps
+// Besides the 64 entry -> exit maps, the chain of hypothesis 0 leaves CHECKPOINTS: for every KiB mark of
+// the segment the first element start at or past it, with the bytes produced up to there.  Parses that
+// enter a segment anywhere fall into step with that chain within a few elements (the format
+// resynchronises), so a parse that enters FAR from the segment's start (pass 2b) only has to be followed
+// element by element until it stands on a checkpoint: from there on it is hypothesis 0.
+static constexpr uint32_t kChkShift = 10;  // one checkpoint per KiB of compressed bytes
 __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *__restrict__ in, uint32_t n,
                                                                  uint32_t n_seg, uint32_t seg_shift,
-                                                                 uint2 *__restrict__ maps)
+                                                                 uint2 *__restrict__ maps, uint2 *__restrict__ chk)
 {
     const uint32_t kSeg = 1u << seg_shift;
     const uint32_t lane = threadIdx.x, s = blockIdx.x;
@@ -114,11 +121,24 @@ __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *
         return;
     const uint32_t seg_base = s * kSeg;
     const uint32_t seg_end = seg_base + kSeg < n ? seg_base + kSeg : n;
+    const uint32_t n_chk = kSeg >> kChkShift;
+    uint2 *my_chk = chk + (size_t)s * n_chk;
+    for (uint32_t i = lane; i < n_chk; i += 64)
+        my_chk[i] = make_uint2(kBad, 0);
     uint32_t pos = seg_base + lane, out = 0;  // hypothetical parse number `lane`
+    uint32_t next_mark = 0;                   // (lane 0) the next KiB mark without a checkpoint
     for (;;) {
         const bool active = pos < seg_end;  // (kBad and exits are >= seg_end)
         if (__ballot(active) == 0)
             break;
+        if (lane == 0 && active) {
+            const uint32_t mk = (pos - seg_base) >> kChkShift;
+            if (mk >= next_mark) {  // first element start at or past mark mk (and any mark skipped before it)
+                for (uint32_t j = next_mark; j <= mk; j++)
+                    my_chk[j] = make_uint2(pos, out);
+                next_mark = mk + 1;
+            }
+        }
         const uint32_t wb = uni(wave_min(active ? pos : kBad));
         uint32_t E, O;
         window_map(in, wb, seg_end, n, lane, E, O);
@@ -132,66 +152,208 @@ __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *
     maps[(size_t)s * 64 + lane] = make_uint2(pos, out);
 }
 
-// ---- 2. the true parse, segment by segment
-// entries[s] = (position, bytes produced) where the true parse enters segment s, (kBad, 0) if it
-// skips the segment inside a literal; result[0] = 0 if the stream parses cleanly to its end.
-__global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t body,
-                                                            uint32_t ulen, uint32_t n_seg, uint32_t seg_shift,
-                                                            const uint2 *__restrict__ maps,
-                                                            uint2 *__restrict__ entries, uint32_t *__restrict__ result)
+// ---- 2. the true parse through the segments, in three short passes instead of one long serial walk
+// A segment map is a function "entry offset (< 64) -> exit position, bytes produced", and such functions
+// compose.  2a: one wave per CHUNK of 64 segments composes its segments' maps for all 64 entry offsets at
+// once (64 dependent look-ups, every chunk in parallel).  2b: ONE wave follows the true parse from chunk
+// to chunk through those chunk maps (a few hundred dependent steps for a GiB, not one per segment).
+// 2c: one wave per chunk walks its segments again from the now known entry and writes entries[s].
+// A hypothesis stops where the parse enters a segment FAR from its start (behind a literal that reaches
+// more than 64 bytes into it); a chunk in which the true parse does that is walked by 2b itself:
+// segment maps where it enters near a segment's start, single elements elsewhere -- and runs of
+// equal-sized elements (a stream of incompressible fragments is one: ~64 KiB literals) 64 at a time,
+// lane k trying the element at p + k * size.
+// entries[s] = (position, bytes produced) where the true parse enters segment s, (kBad, 0) where no
+// element starts in the segment; result[0] = 0 if the stream parses cleanly to its end.
+static constexpr uint32_t kChunkSegs = 64;
+static constexpr uint32_t kStRun = 0, kStFar = 1, kStBad = 2;
+
+struct ChunkMap {
+    uint32_t pos, out, st, pad;
+};
+
+__global__ __launch_bounds__(64) void stream_chunk_maps_kernel(uint32_t n, uint32_t n_seg, uint32_t seg_shift,
+                                                               const uint2 *__restrict__ maps,
+                                                               ChunkMap *__restrict__ cmaps)
 {
     const uint32_t kSeg = 1u << seg_shift;
-    // The walk is a chain of dependent look-ups; straight from global memory each costs a memory
-    // latency.  The maps of 64 segments (32 KiB) are therefore staged in LDS with one burst of
-    // coalesced loads and stepped through from there.
-    __shared__ uint2 lmap[64 * 64];
-    const uint32_t lane = threadIdx.x;
-    uint32_t p = body, out = 0;
-    bool ok = true;
-    for (uint32_t s0 = 0; s0 < n_seg && ok; s0 += 64) {
-        const uint32_t cnt = n_seg - s0 < 64 ? n_seg - s0 : 64;
-        bool staged = false;  // on first use: a run of long literals (incompressible data) never looks a map up
-        for (uint32_t k = 0; k < cnt && ok; k++) {
-            const uint32_t s = s0 + k;
-            const uint32_t seg_base = s * kSeg;
-            const uint32_t seg_end = seg_base + kSeg < n ? seg_base + kSeg : n;
-            if (p >= seg_end) {
-                if (lane == 0)
-                    entries[s] = make_uint2(kBad, 0);
-                continue;
-            }
-            if (lane == 0)
-                entries[s] = make_uint2(p, out);
-            if (p - seg_base < 64) {
-                if (!staged) {
-                    const u32x4 *g = reinterpret_cast<const u32x4 *>(maps + (size_t)s0 * 64);
-                    u32x4 *l = reinterpret_cast<u32x4 *>(lmap);
-                    for (uint32_t i = lane; i < cnt * 32; i += 64)  // 32 x 16 bytes per segment
-                        l[i] = g[i];
-                    __syncthreads();
-                    staged = true;
+    const uint32_t lane = threadIdx.x, c = blockIdx.x;
+    const uint32_t s0 = c * kChunkSegs, s1 = s0 + kChunkSegs < n_seg ? s0 + kChunkSegs : n_seg;
+    uint32_t pos = s0 * kSeg + lane, out = 0, st = kStRun;  // hypothesis: the parse enters the chunk at byte `lane`
+    for (uint32_t s = s0; s < s1; s++) {
+        const uint32_t seg_base = s * kSeg;
+        const uint32_t seg_end = seg_base + kSeg < n ? seg_base + kSeg : n;
+        if (st == kStRun && pos < seg_end) {  // (pos >= seg_end: the segment lies inside an element)
+            const uint32_t rel = pos - seg_base;
+            if (rel < 64) {
+                const uint2 m = maps[(size_t)s * 64 + rel];
+                if (m.x == kBad) {
+                    st = kStBad;
+                } else {
+                    pos = m.x;
+                    out += m.y;
                 }
-                const uint2 m = lmap[k * 64 + (p - seg_base)];
-                const uint32_t ex = uni(m.x), os = uni(m.y);
-                ok = ex != kBad;
-                p = ex;
-                out += os;
-            } else {  // entered far into the segment (after a long literal): parse its rest here
-                while (ok && p < seg_end) {
-                    uint32_t E, O;
-                    window_map(in, p, seg_end, n, lane, E, O);
-                    const uint32_t e = lane_get(E, 0), o = lane_get(O, 0);
-                    ok = e != kBad;
-                    out += o;
-                    p += e;
-                }
+            } else {
+                st = kStFar;  // far into the segment: no map covers this entry
             }
         }
-        __syncthreads();
+    }
+    cmaps[(size_t)c * 64 + lane] = ChunkMap{pos, out, st, 0};
+}
+
+// The parse from p (bytes produced: out) up to the first element that starts at or past `until`,
+// recording in entries[] the first element that starts in each segment.  One wave, wave-uniform state.
+__device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, uint32_t n, uint32_t seg_shift,
+                                              const uint2 *__restrict__ maps, const uint2 *__restrict__ chk,
+                                              uint2 *__restrict__ entries, uint32_t &p, uint32_t &out,
+                                              uint32_t until, uint32_t lane)
+{
+    const uint32_t kSeg = 1u << seg_shift;
+    uint32_t last_seg = kBad;
+    while (p < until) {
+        const uint32_t s = p >> seg_shift;
+        const uint32_t seg_base = s * kSeg;
+        if (s != last_seg) {
+            if (lane == 0)
+                entries[s] = make_uint2(p, out);
+            last_seg = s;
+        }
+        const uint32_t rel = p - seg_base;
+        if (rel < 64) {  // the segment's map covers the rest of the segment
+            const uint2 m = maps[(size_t)s * 64 + rel];
+            const uint32_t ex = uni(m.x), os = uni(m.y);
+            if (ex == kBad)
+                return false;
+            p = ex;
+            out += os;
+            continue;
+        }
+        // far from the segment's start: the element at p, and -- lane k -- the ones at p + k * size,
+        // as long as they have the same size (what a run of equal literals or copies looks like)
+        const Elem e0 = element_at(in, p, n);
+        const uint32_t size0 = uni(e0.size);
+        if (!__builtin_amdgcn_readfirstlane(e0.ok ? 1 : 0))
+            return false;
+        if (size0 < 64) {
+            // small elements (the inside of a compressible fragment): 64-byte window steps until the
+            // parse stands on a checkpoint of the segment's hypothesis 0 -- then that hypothesis' exit is
+            // this parse's exit -- or reaches the end of the segment
+            const uint32_t seg_end = seg_base + kSeg < until ? seg_base + kSeg : until;
+            const uint32_t n_chk = kSeg >> kChkShift;
+            uint32_t mark = ((p - seg_base) >> kChkShift) + 1;  // the next KiB mark ahead
+            bool merged = false;
+            while (p < seg_end) {
+                uint32_t E, O;
+                window_map(in, p, seg_end, n, lane, E, O);
+                const uint32_t ex = lane_get(E, 0), os = lane_get(O, 0);
+                if (ex == kBad)
+                    return false;
+                out += os;
+                p += ex;
+                if (p < seg_end && ((p - seg_base) >> kChkShift) >= mark) {
+                    const uint32_t mk = (p - seg_base) >> kChkShift;
+                    // (this parse's first element at or past mark `mark`; the checkpoint of a later mark it
+                    // may have jumped over is the same element or none of its own)
+                    const uint2 c = chk[(size_t)s * n_chk + mark];
+                    if (uni(c.x) == p) {
+                        const uint2 m = maps[(size_t)s * 64];  // hypothesis 0: (exit, bytes produced)
+                        if (uni(m.x) == kBad)
+                            return false;
+                        out += uni(m.y) - uni(c.y);
+                        p = uni(m.x);
+                        merged = true;
+                        break;
+                    }
+                    mark = mk + 1;
+                }
+            }
+            (void)merged;
+            continue;
+        }
+        const uint64_t q64 = (uint64_t)p + (uint64_t)lane * size0;
+        const bool inside = q64 < until;  // (until <= n)
+        const uint32_t q = inside ? (uint32_t)q64 : p;
+        const Elem e = element_at(in, q, n);
+        const uint64_t good = ballot64(inside && e.ok && e.size == size0);
+        const uint32_t cnt = good == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~good);  // >= 1: lane 0 is the element at p
+        const bool mine = lane < cnt;
+        const uint32_t olen = mine ? e.olen : 0u;
+        const uint32_t incl = wave_inclusive_sum(olen);
+        const uint32_t my_seg = q >> seg_shift;
+        const uint32_t prev_seg = lane == 0 ? last_seg : (uint32_t)((q64 - size0) >> seg_shift);
+        if (mine && my_seg != prev_seg)
+            entries[my_seg] = make_uint2(q, out + (incl - olen));
+        asm volatile("");  // (keeps the per-lane store's join apart from the loop's uniform state)
+        last_seg = (uint32_t)(((uint64_t)p + (uint64_t)(cnt - 1) * size0) >> seg_shift);
+        out += lane_get(incl, 63);
+        p += cnt * size0;  // (< 2^32: every consumed element ends inside the stream)
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t body,
+                                                            uint32_t ulen, uint32_t n_seg, uint32_t seg_shift,
+                                                            const uint2 *__restrict__ maps, const uint2 *__restrict__ chk,
+                                                            const ChunkMap *__restrict__ cmaps,
+                                                            uint2 *__restrict__ entries, uint2 *__restrict__ centries,
+                                                            uint32_t *__restrict__ result)
+{
+    const uint32_t kSeg = 1u << seg_shift;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_chunk = (n_seg + kChunkSegs - 1) / kChunkSegs;
+    uint32_t p = body, out = 0;
+    bool ok = true;
+    for (uint32_t c = 0; c < n_chunk && ok; c++) {
+        const uint64_t cb64 = (uint64_t)c * kChunkSegs * kSeg;
+        const uint64_t ce64 = cb64 + (uint64_t)kChunkSegs * kSeg;
+        const uint32_t chunk_base = (uint32_t)cb64, chunk_end = ce64 < n ? (uint32_t)ce64 : n;
+        uint2 ce = make_uint2(kBad, 0);  // nothing for pass 2c to do in this chunk
+        if (p < chunk_end) {
+            bool regular = false;
+            if (p - chunk_base < 64) {
+                const ChunkMap cm = cmaps[(size_t)c * 64 + (p - chunk_base)];
+                if (uni(cm.st) == kStRun) {  // the whole chunk through near entries: pass 2c fills its entries
+                    ce = make_uint2(p, out);
+                    p = uni(cm.pos);
+                    out += uni(cm.out);
+                    regular = true;
+                }
+            }
+            if (!regular)
+                ok = walk_segments(in, n, seg_shift, maps, chk, entries, p, out, chunk_end, lane);
+        }
+        if (lane == 0)
+            centries[c] = ce;
     }
     ok = ok && p == n && out == ulen;
     if (lane == 0)
         result[0] = ok ? 0u : 1u;
+}
+
+// 2c: the segments of the chunks that pass 2b crossed through their chunk map
+__global__ __launch_bounds__(64) void stream_chunk_entries_kernel(uint32_t n, uint32_t n_seg, uint32_t seg_shift,
+                                                                  const uint2 *__restrict__ maps,
+                                                                  const uint2 *__restrict__ centries,
+                                                                  uint2 *__restrict__ entries)
+{
+    const uint32_t kSeg = 1u << seg_shift;
+    const uint32_t lane = threadIdx.x, c = blockIdx.x;
+    const uint2 ce = centries[c];
+    uint32_t p = uni(ce.x), out = uni(ce.y);
+    if (p == kBad)
+        return;
+    const uint32_t s0 = c * kChunkSegs, s1 = s0 + kChunkSegs < n_seg ? s0 + kChunkSegs : n_seg;
+    for (uint32_t s = s0; s < s1; s++) {
+        const uint32_t seg_base = s * kSeg;
+        const uint32_t seg_end = seg_base + kSeg < n ? seg_base + kSeg : n;
+        if (p >= seg_end)
+            continue;  // inside an element: entries[s] stays (kBad, 0)
+        if (lane == 0)
+            entries[s] = make_uint2(p, out);
+        const uint2 m = maps[(size_t)s * 64 + (p - seg_base)];  // (near entry, not kBad: pass 2a ran this path)
+        p = uni(m.x);
+        out += uni(m.y);
+    }
 }
 
 // ---- 3. fragment boundaries inside each segment
@@ -258,13 +420,17 @@ __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__
     }
 }
 
-// off[0] = body, off[n_frag] = n, everything between "not found"; result[0..2] = 0
+// off[0] = body, off[n_frag] = n, everything between "not found"; entries[] = "no element starts here";
+// result[0..2] = 0
 __global__ __launch_bounds__(256) void stream_index_init_kernel(unsigned long long *__restrict__ off, uint32_t n_frag,
-                                                                uint32_t body, uint32_t n, uint32_t *__restrict__ result)
+                                                                uint32_t body, uint32_t n, uint2 *__restrict__ entries,
+                                                                uint32_t n_seg, uint32_t *__restrict__ result)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i <= n_frag)
         off[i] = i == 0 ? body : (i == n_frag ? n : ~0ull);
+    if (i < n_seg)
+        entries[i] = make_uint2(kBad, 0);
     if (i < 3)
         result[i] = 0;
 }
@@ -285,7 +451,9 @@ size_t stream_index_scratch_bytes(uint64_t n)
 {
     const uint64_t seg = 1ull << 14;  // sized for the smallest segments (the choice may be overridden in tests)
     const size_t n_seg = (size_t)((n + seg - 1) / seg);
-    return n_seg * 64 * sizeof(uint2) + n_seg * sizeof(uint2) + 64;
+    const size_t n_chunk = (n_seg + kChunkSegs - 1) / kChunkSegs;
+    return n_seg * 64 * sizeof(uint2) + n_seg * sizeof(uint2) + n_chunk * (64 * sizeof(ChunkMap) + sizeof(uint2)) +
+           (size_t)((n + 1023) / 1024 + 64) * sizeof(uint2) + 64;  // maps, entries, chunk maps + entries, checkpoints
 }
 
 // d_in: the whole raw stream (n < 2^31 bytes, readable up to n + 8), body = size of its preamble,
@@ -298,15 +466,25 @@ hipError_t launch_stream_index(const void *d_in, uint64_t n, uint32_t body, uint
     const uint32_t seg_shift = seg_shift_for(n);
     const uint32_t n_seg = (uint32_t)((n + (1ull << seg_shift) - 1) >> seg_shift);
     const uint32_t n_frag = (uint32_t)((ulen + kMaxBlock - 1) / kMaxBlock);
+    const uint32_t n_chunk = (n_seg + kChunkSegs - 1) / kChunkSegs;
     uint2 *maps = static_cast<uint2 *>(d_scratch);
     uint2 *entries = maps + (size_t)n_seg * 64;
+    ChunkMap *cmaps = reinterpret_cast<ChunkMap *>(entries + n_seg);
+    uint2 *centries = reinterpret_cast<uint2 *>(cmaps + (size_t)n_chunk * 64);
+    uint2 *chk = centries + n_chunk;  // (1 << seg_shift) / 1 KiB checkpoints per segment
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     unsigned long long *off = reinterpret_cast<unsigned long long *>(d_off);
-    hipLaunchKernelGGL(stream_index_init_kernel, dim3(n_frag / 256 + 1), dim3(256), 0, stream, off, n_frag, body,
-                       (uint32_t)n, d_result);
-    hipLaunchKernelGGL(stream_segment_maps_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, n_seg, seg_shift, maps);
+    const uint32_t n_init = n_frag + 1 > n_seg ? n_frag + 1 : n_seg;
+    hipLaunchKernelGGL(stream_index_init_kernel, dim3(n_init / 256 + 1), dim3(256), 0, stream, off, n_frag, body,
+                       (uint32_t)n, entries, n_seg, d_result);
+    hipLaunchKernelGGL(stream_segment_maps_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, n_seg, seg_shift, maps,
+                       chk);
+    hipLaunchKernelGGL(stream_chunk_maps_kernel, dim3(n_chunk), dim3(64), 0, stream, (uint32_t)n, n_seg, seg_shift, maps,
+                       cmaps);
     hipLaunchKernelGGL(stream_resolve_kernel, dim3(1), dim3(64), 0, stream, in, (uint32_t)n, body, (uint32_t)ulen,
-                       n_seg, seg_shift, maps, entries, d_result);
+                       n_seg, seg_shift, maps, chk, cmaps, entries, centries, d_result);
+    hipLaunchKernelGGL(stream_chunk_entries_kernel, dim3(n_chunk), dim3(64), 0, stream, (uint32_t)n, n_seg, seg_shift,
+                       maps, centries, entries);
     hipLaunchKernelGGL(stream_boundaries_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, (uint32_t)ulen,
                        n_seg, seg_shift, entries, off, d_result + 1);
     return hipGetLastError();
