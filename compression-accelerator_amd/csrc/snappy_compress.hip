@@ -356,7 +356,10 @@ struct HashTab {
 // soon as it has emitted its first copy and marks it for the multi-wave kernel.
 static constexpr uint32_t kRoutedMarker = 0xfffffffdu;  // in out_len[b]: "compressible, not done yet"
 
-template <int kBlkChunks, bool kLean, typename Tab, bool kRoute = false>
+// kFast: with the fast dense path (compressible data).  The single kernel's instance for launches that
+// a sample found incompressible is built without it: its presence alone costs that instance 2 % (register
+// allocation of the strided path), and such blocks do not use it.
+template <int kBlkChunks, bool kLean, typename Tab, bool kRoute = false, bool kFast = true>
 __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uint8_t *__restrict__ in,
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
                                                        uint32_t lane)
@@ -462,7 +465,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             for (int u = 0; u < kBlkChunks; u++) {
                 blk[u] = u32x4{0, 0, 0, 0};
                 if ((uint32_t)u < nchunk)
-                    blk[u] = ld128_nt(bp + 1024 * u);
+                    // (plain loads, not non-temporal ones: the lines the probe loads below touch are then
+                    // served by the same fetch instead of being fetched twice -- C3 0.86 -> 0.82 ms)
+                    blk[u] = ld128(bp + 1024 * u);
             }
         }
         const uint32_t blk_op = op;  // the literal must start here for the prediction to hold
@@ -559,7 +564,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
 #endif
 
 #ifndef SZ_NO_FAST
-            if (chain && !hold_fast && P + kFastMargin <= ip_limit) {
+            if (kFast && chain && !hold_fast && P + kFastMargin <= ip_limit) {
                 // =================================================== FAST DENSE PATH (fixed tiles)
                 // Compressible data spends its time here.  The block is cut into fixed tiles of 64
                 // positions (lane l of tile t = position 64 t + l), so the bytes of a tile come out of
@@ -1472,9 +1477,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     const HashTab<true> tab{lds_tab, nullptr, nullptr};
     uint32_t op;
-    if (route)  // auto mode: compressible blocks are left to the multi-wave kernel (kRoutedMarker)
+    if (route)  // route mode: compressible blocks are left to the multi-wave kernel (kRoutedMarker)
         op = compress_one_block<64, false, HashTab<true>, true>(tab, src + (uint64_t)b * in_stride, n,
                                                                  dst + (uint64_t)b * dst_stride, flags, lane);
+    else if (select)  // auto mode, and the sample says incompressible: the instance without the fast dense path
+        op = compress_one_block<64, false, HashTab<true>, false, false>(tab, src + (uint64_t)b * in_stride, n,
+                                                                         dst + (uint64_t)b * dst_stride, flags, lane);
     else
         op = compress_one_block<64, false>(tab, src + (uint64_t)b * in_stride, n, dst + (uint64_t)b * dst_stride,
                                            flags, lane);
