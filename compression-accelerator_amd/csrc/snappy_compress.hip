@@ -8,7 +8,7 @@
 // Mapping to the machine (details at compress_one_block and the two kernels below)
 //   * one 64-lane wavefront per <=64 KiB block; the 16384 x uint16 hash table in LDS (32 KiB: four
 //     blocks per CU = one wave per SIMD) or, for the extra waves of the multi-wave kernel, in a
-//     generation-tagged table in global memory;
+//     table of the same shape in global memory (L2), zeroed per block by its wave;
 //   * the greedy parse is serial in the reference; here 64 positions are probed at once -- 64
 //     consecutive bytes ("dense window", scalar walk over the ballot mask, prefix-sum packing of
 //     the elements) or the next 64 probes of the skip schedule ("strided batch") -- and the table
@@ -321,13 +321,18 @@ struct HashTab {
     uint32_t *bm;  // global home only: 16384-bit scratch bitmap in LDS (all zero between uses)
     static constexpr bool kInLds = in_lds;
 
-    // (relaxed wave-scope atomics = plain loads/stores that the compiler may neither forward nor
-    // merge: other lanes of this wave write the same entries)
+    // (relaxed atomics = plain loads/stores that the compiler may neither forward nor merge: other
+    // lanes of this wave write the same entries.  LDS: wave scope, the LDS executes a wave's accesses in
+    // order.  Global memory: the look-up is an AGENT-scope load -- `global_load_ushort ... sc1`, served by
+    // the L2 and never by a line the CU's vector L1 may still hold from before this wave's store; the
+    // wave's stores (write-through) and loads of one address reach the L2 in issue order.  Measured
+    // against the wave-scope load: no difference in rate (these lines miss the L1 anyway: 8 x 32 KiB of
+    // tables per CU).  tests/test_abi.py checks the instruction.)
     __device__ __forceinline__ uint32_t get(uint32_t h) const
     {
         if (in_lds)
             return __hip_atomic_load(lds + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        return __hip_atomic_load(glob + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        return __hip_atomic_load(glob + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __device__ __forceinline__ void put(uint32_t h, uint32_t v) const
     {

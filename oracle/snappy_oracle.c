@@ -380,13 +380,29 @@ int oracle_compress_blocks(const uint8_t *src, size_t in_stride, const uint32_t 
  * reused by every repetition, the repetitions are separated by a barrier, and
  * the clock runs around all of them: nothing is allocated or spawned inside the
  * timed region. */
+typedef int (*ext_compress_fn)(const char *, size_t, char *, size_t *); /* libsnappy's C API: snappy_compress */
+
 struct tjob {
     struct job j;
+    ext_compress_fn ext; /* NULL: the oracle itself */
     int reps, cpu;
     pthread_barrier_t *bar;
     double *seconds;
     int leader;
 };
+
+/* one pass over this thread's blocks with an external compressor (same buffers, same partition) */
+static void ext_pass(struct tjob *t)
+{
+    struct job *j = &t->j;
+    for (uint32_t b = j->begin; b < j->end; b++) {
+        size_t cap = j->dst_stride;
+        if (t->ext((const char *)(j->src + (size_t)b * j->in_stride), j->in_stride,
+                   (char *)(j->dst + (size_t)b * j->dst_stride), &cap) != 0)
+            cap = 0;
+        j->out_len[b] = (uint32_t)cap;
+    }
+}
 
 static void *tjob_main(void *arg)
 {
@@ -397,13 +413,19 @@ static void *tjob_main(void *arg)
         CPU_SET(t->cpu, &set);
         (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
     }
-    job_main(&t->j); /* warm-up pass: page in the output, warm the caches */
+    if (t->ext)
+        ext_pass(t);
+    else
+        job_main(&t->j); /* warm-up pass: page in the output, warm the caches */
     pthread_barrier_wait(t->bar);
     struct timespec t0, t1;
     if (t->leader)
         clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int r = 0; r < t->reps; r++) {
-        job_main(&t->j);
+        if (t->ext)
+            ext_pass(t);
+        else
+            job_main(&t->j);
         pthread_barrier_wait(t->bar);
     }
     if (t->leader) {
@@ -413,9 +435,33 @@ static void *tjob_main(void *arg)
     return NULL;
 }
 
+static int time_blocks(ext_compress_fn ext, const uint8_t *src, size_t in_stride, uint32_t n_blocks, uint8_t *dst,
+                       size_t dst_stride, uint32_t *out_len, int per_block_varint, int n_threads, int reps,
+                       double *seconds);
+
 int oracle_time_compress_blocks(const uint8_t *src, size_t in_stride, uint32_t n_blocks, uint8_t *dst,
                                 size_t dst_stride, uint32_t *out_len, int per_block_varint,
                                 int n_threads, int reps, double *seconds)
+{
+    return time_blocks(NULL, src, in_stride, n_blocks, dst, dst_stride, out_len, per_block_varint, n_threads, reps,
+                       seconds);
+}
+
+/* The same harness around an external compressor with libsnappy's C signature (bench.py passes the
+ * address of the image's snappy_compress): the real google/snappy timed exactly like the port. */
+int oracle_time_external_blocks(void *snappy_compress_fn, const uint8_t *src, size_t in_stride, uint32_t n_blocks,
+                                uint8_t *dst, size_t dst_stride, uint32_t *out_len, int n_threads, int reps,
+                                double *seconds)
+{
+    if (!snappy_compress_fn)
+        return -1;
+    return time_blocks((ext_compress_fn)snappy_compress_fn, src, in_stride, n_blocks, dst, dst_stride, out_len, 0,
+                       n_threads, reps, seconds);
+}
+
+static int time_blocks(ext_compress_fn ext, const uint8_t *src, size_t in_stride, uint32_t n_blocks, uint8_t *dst,
+                       size_t dst_stride, uint32_t *out_len, int per_block_varint, int n_threads, int reps,
+                       double *seconds)
 {
     if (n_threads < 1 || reps < 1 || !seconds || in_stride > ORACLE_BLOCK || n_blocks < (uint32_t)n_threads)
         return -1;
@@ -438,6 +484,7 @@ int oracle_time_compress_blocks(const uint8_t *src, size_t in_stride, uint32_t n
         jobs[t].j = (struct job){src, in_stride, NULL, dst, dst_stride, out_len, per_block_varint,
                                  (uint32_t)((uint64_t)n_blocks * t / n_threads),
                                  (uint32_t)((uint64_t)n_blocks * (t + 1) / n_threads)};
+        jobs[t].ext = ext;
         jobs[t].reps = reps;
         jobs[t].cpu = n_cpus >= n_threads ? cpus[t] : -1;
         jobs[t].bar = &bar;

@@ -54,6 +54,13 @@ int oracle_time_compress_blocks(const uint8_t *src, size_t in_stride, uint32_t n
                                 size_t dst_stride, uint32_t *out_len, int per_block_varint,
                                 int n_threads, int reps, double *seconds);
 
+/* Same harness around an external compressor with libsnappy's C signature
+ * int snappy_compress(const char*, size_t, char*, size_t*) -- the image's real
+ * google/snappy, timed exactly like the port (bench.py cpu_baseline). */
+int oracle_time_external_blocks(void *snappy_compress_fn, const uint8_t *src, size_t in_stride, uint32_t n_blocks,
+                                uint8_t *dst, size_t dst_stride, uint32_t *out_len, int n_threads, int reps,
+                                double *seconds);
+
 /* FNV-1a 64 (offset basis 1469598103934665603, prime 1099511628211). */
 uint64_t oracle_fnv1a64(const uint8_t *p, size_t n);
 

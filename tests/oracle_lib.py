@@ -46,6 +46,9 @@ def lib():
     L.oracle_time_compress_blocks.argtypes = [u8p, ctypes.c_size_t, ctypes.c_uint32, u8p, ctypes.c_size_t, u8p,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
     L.oracle_time_compress_blocks.restype = ctypes.c_int
+    L.oracle_time_external_blocks.argtypes = [ctypes.c_void_p, u8p, ctypes.c_size_t, ctypes.c_uint32, u8p, ctypes.c_size_t,
+                                              u8p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    L.oracle_time_external_blocks.restype = ctypes.c_int
     L.oracle_fnv1a64.argtypes = [u8p, ctypes.c_size_t]
     L.oracle_fnv1a64.restype = ctypes.c_uint64
     _lib = L
@@ -122,6 +125,21 @@ def time_compress_blocks(src, in_stride, n_blocks, threads, reps, per_block_vari
                                            ctypes.byref(sec))
     if rc != 0:
         raise RuntimeError("oracle_time_compress_blocks rc=%d" % rc)
+    return sec.value, out_len
+
+
+def time_external_blocks(fn_addr, src, in_stride, n_blocks, threads, reps):
+    """Seconds for `reps` passes of an external compressor with libsnappy's C signature (fn_addr = the
+    address of snappy_compress) in the same pinned-thread harness as time_compress_blocks."""
+    a = _as_u8(src)
+    dst_stride = max_compressed_length(in_stride) + 6
+    dst = np.empty((n_blocks, dst_stride), dtype=np.uint8)
+    out_len = np.zeros(n_blocks, dtype=np.uint32)
+    sec = ctypes.c_double(0.0)
+    rc = lib().oracle_time_external_blocks(fn_addr, a.ctypes.data, in_stride, n_blocks, dst.ctypes.data, dst_stride,
+                                           out_len.ctypes.data, threads, reps, ctypes.byref(sec))
+    if rc != 0:
+        raise RuntimeError("oracle_time_external_blocks rc=%d" % rc)
     return sec.value, out_len
 
 

@@ -136,6 +136,19 @@ def test_no_reloaded_spill_feeds_a_memory_instruction_scalar_base(tmp_path):
     assert not offenders, "\n".join(offenders)
 
 
+def test_global_hash_table_lookups_bypass_the_vector_l1(tmp_path):
+    """The multi-wave kernel's extra waves keep their hash tables in global memory and read back entries
+    that other lanes of the same wave stored a moment ago.  The look-up must come from the L2 (where the
+    wave's write-through stores arrive in issue order), not from a line the CU's vector L1 holds from
+    before the store: every 16-bit global load of the compress kernels carries sc1 (agent scope)."""
+    src = os.path.join(build_util.ROOT, "compression-accelerator_amd", "csrc", "snappy_compress.hip")
+    lines = _isa_of(src, tmp_path)
+    loads = [l.strip() for l in lines if re.match(r"^\s*global_load_ushort\s", l)]
+    assert len(loads) >= 4, "no table look-ups found: did the table change its entry type?"
+    bad = [l for l in loads if " sc1" not in l]
+    assert not bad, "\n".join(bad)
+
+
 def test_parse_state_of_the_compress_kernels_is_provably_wave_uniform(tmp_path):
     """The compress kernels keep their parse state (positions, masks, flags) in scalar registers only
     while the compiler can PROVE it wave-uniform; one join of a per-lane branch merged with a uniform

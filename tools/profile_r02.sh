@@ -1,0 +1,21 @@
+# Round-2 evidence under profiles/ (run on the GPU box through gpurun): kernel-trace stats of the
+# bench command and of the text workload, PMC passes for C3 (HBM traffic; one counter group per pass)
+# and for text (instruction mix), the single-stream decoder's kernels, and the bench line itself.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_r02
+rm -rf $O; mkdir -p $O
+timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o c3 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --no-extra > $O/c3.log 2>&1 || echo "c3 stats failed"
+echo "c3 stats done"
+timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $O/text -o text -- python3 $R/tools/quickbench.py text 16384 5 > $O/text.log 2>&1 || echo "text stats failed"
+echo "text stats done"
+timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -o stream -- python3 $R/tools/streamdecomp.py 1024 > $O/stream.log 2>&1 || echo "stream stats failed"
+echo "stream stats done"
+for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  timeout -k 10 250 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$tag -o p -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extra > $O/pmc_$tag.log 2>&1 || echo "pmc $tag failed"
+  echo "pmc $tag done"
+done
+bash $R/tools/pmc_r2.sh r02_text text 4096 > $O/pmc_text.log 2>&1; echo "pmc text done"
+timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+tail -c 600 $O/bench.json
