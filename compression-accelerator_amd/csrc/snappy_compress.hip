@@ -32,6 +32,14 @@ namespace szk {
 // merged there differs between lanes (vector registers, 64-bit vector arithmetic for the masks).
 #define UNIFORM_JOIN() asm volatile("")
 
+// KiB of each string one step of a long match extension keeps in flight (match_length)
+#ifndef SZ_LDS_WAVE_PRIO
+#define SZ_LDS_WAVE_PRIO 3
+#endif
+#ifndef SZ_MATCH_PIECES
+#define SZ_MATCH_PIECES 4
+#endif
+
 // Analysis builds only (-DSZ_MARK): comments in the ISA at the phases of the fast dense path.
 #ifdef SZ_MARK
 #define MARK(name) asm volatile("; MARK " name)
@@ -40,7 +48,9 @@ namespace szk {
 #endif
 
 #ifdef SZ_PROF
-__device__ unsigned long long g_prof[128];  // [0,64): waves with the table in LDS (32 sums, 32 counts), [64,128): in global memory
+__device__ unsigned long long g_prof[160];  // [128,160): phases of match_length (16 sums, 16 counts), all waves
+#define ML_START() unsigned long long mlt_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mlt_) :: "memory")
+#define ML_LAP(i) do { unsigned long long t2_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); if (lane == 0) { atomicAdd(&g_prof[128 + (i)], t2_ - mlt_); atomicAdd(&g_prof[144 + (i)], 1ull); } mlt_ = t2_; } while (0)  // [0,64): waves with the table in LDS (32 sums, 32 counts), [64,128): in global memory
 #define PROF_DECL unsigned long long pt_ = 0, pacc_[32] = {}; unsigned pcnt_[32] = {};
 #define PROF_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt_) :: "memory"); } while (0)
 #define PROF_LAP(i) do { unsigned long long t2_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
@@ -54,6 +64,8 @@ __device__ unsigned long long g_prof[128];  // [0,64): waves with the table in L
 #define PROF_LAPV(i) do { } while (0)
 #define PROF_ADD(i, v) do { } while (0)
 #define PROF_FLUSH() do { } while (0)
+#define ML_START() do { } while (0)
+#define ML_LAP(i) do { } while (0)
 #endif
 
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
@@ -202,16 +214,21 @@ __device__ __forceinline__ uint32_t emit_copy(uint8_t *__restrict__ out, uint32_
 }
 
 // Match extension (a5): `m` bytes are already known equal; compares on up to the block end n.
+template <int kPieces>
 __device__ __forceinline__ uint32_t match_length(const uint8_t *__restrict__ in, uint32_t cand,
                                                  uint32_t ip, uint32_t n, uint32_t lane, uint32_t m)
 {
+    ML_START();
     {
+        // 49..64 bytes, so that the 16-byte loads of the ip string below are aligned
+        const uint32_t l1 = 64 - ((ip + m) & 15u);
         const uint32_t i = m + lane;
-        const bool eq = (ip + i < n) && in[cand + i] == in[ip + i];
+        const bool eq = lane >= l1 || ((ip + i < n) && in[cand + i] == in[ip + i]);
         const uint64_t ne = ~__ballot(eq);
+        ML_LAP(0);
         if (ne)
             return m + ctz64(ne);
-        m += 64;
+        m += l1;
     }
     // long match: 16 B per lane and KiB; 4 KiB of both strings in flight per step while that much is left
     auto eq16 = [&](const u32x4 &a, const u32x4 &b) -> uint32_t {  // equal leading bytes of two 16-byte strings
@@ -223,45 +240,74 @@ __device__ __forceinline__ uint32_t match_length(const uint8_t *__restrict__ in,
         if (d0) eqb = (__builtin_ctz(d0) >> 3);
         return eqb;
     };
-    while (ip + m + 4096 <= n) {
-        u32x4 a[4], b[4];
+    // Every step below is one dependent round trip to memory, and bytes of this block that nobody has
+    // touched yet come from HBM (2-3 us under load): after the first whole 4 KiB matched, one line
+    // per lane of the REST of the block's own input is requested at once, so that the steps that
+    // follow find their bytes on the way in or in the L2 (the other string is this same data d bytes
+    // earlier).  Nothing is fetched that the block would not read anyway.
+    // Every step is one dependent round trip to memory (several thousand cycles under load, more for
+    // bytes of this block nobody has touched yet), so a step keeps kPieces KiB of both strings in
+    // flight; what a step costs in instructions is small beside that: one OR-reduction and one ballot,
+    // the place of the difference is only worked out in the step that has one.
+    auto locate = [&](const u32x4 (&a)[kPieces], const u32x4 (&b)[kPieces]) -> uint32_t {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            a[k] = ld128(in + cand + m + 1024 * k + 16 * lane);
-            b[k] = ld128(in + ip + m + 1024 * k + 16 * lane);
-        }
-        uint32_t res = 0xffffffffu;  // length at the first difference, if there is one in these 4 KiB
-#pragma unroll
-        for (int k = 3; k >= 0; k--) {
+        for (int k = 0; k < kPieces; k++) {
             const uint32_t eqb = eq16(a[k], b[k]);
             const uint64_t ne = ballot64(eqb < 16);
             if (ne) {
                 const uint32_t f = ctz64(ne);
-                res = m + 1024 * k + 16 * f + lane_get(eqb, f);
+                return m + 1024 * k + 16 * f + lane_get(eqb, f);
             }
         }
-        if (res != 0xffffffffu)
-            return res;
-        m += 4096;
-    }
-    while (ip + m + 1024 <= n) {
-        const u32x4 a = ld128(in + cand + m + 16 * lane);
-        const u32x4 b = ld128(in + ip + m + 16 * lane);
-        const uint32_t eqb = eq16(a, b);
-        const uint64_t ne = ballot64(eqb < 16);
-        if (ne) {
-            const uint32_t f = ctz64(ne);
-            return m + 16 * f + lane_get(eqb, f);
+        return m;  // (not reached: the caller saw a difference)
+    };
+    auto differ = [&](const u32x4 (&a)[kPieces], const u32x4 (&b)[kPieces]) -> bool {
+        uint32_t d = 0;
+#pragma unroll
+        for (int k = 0; k < kPieces; k++)
+            d |= (a[k].x ^ b[k].x) | (a[k].y ^ b[k].y) | (a[k].z ^ b[k].z) | (a[k].w ^ b[k].w);
+        return ballot64(d != 0) != 0;
+    };
+    while (ip + m + 1024 * kPieces <= n) {
+        u32x4 a[kPieces], b[kPieces];
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            a[k] = ld128(in + cand + m + 1024 * k + 16 * lane);
+            b[k] = ld128(in + ip + m + 1024 * k + 16 * lane);
         }
-        m += 1024;
+        if (differ(a, b)) {
+            ML_LAP(2);
+            return locate(a, b);
+        }
+        ML_LAP(1);
+        m += 1024 * kPieces;
     }
-    for (;;) {
-        const uint32_t i = m + lane;
-        const bool eq = (ip + i < n) && in[cand + i] == in[ip + i];
-        const uint64_t ne = ~__ballot(eq);
-        if (ne)
-            return m + ctz64(ne);
-        m += 64;
+    // the last < kPieces KiB: the 16-byte pieces that lie wholly inside the block and the < 16 bytes
+    // after them, all in flight together
+    {
+        const uint32_t rem = n - (ip + m), whole = rem & ~15u, r15 = rem & 15u;
+        u32x4 a[kPieces], b[kPieces];
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            a[k] = b[k] = u32x4{0, 0, 0, 0};
+            if (1024u * k + 16u <= rem) {
+                if (1024u * k + 16u * lane + 16u <= rem) {
+                    a[k] = ld128(in + cand + m + 1024 * k + 16 * lane);
+                    b[k] = ld128(in + ip + m + 1024 * k + 16 * lane);
+                }
+                UNIFORM_JOIN();
+            }
+        }
+        uint32_t ca = 0, cb = 1;  // lanes at and past r15 differ: the block ends there
+        if (lane < r15) {
+            ca = in[cand + m + whole + lane];
+            cb = in[ip + m + whole + lane];
+        }
+        UNIFORM_JOIN();
+        ML_LAP(3);
+        if (differ(a, b))
+            return locate(a, b);
+        return m + whole + ctz64(ballot64(ca != cb));
     }
 }
 
@@ -364,7 +410,8 @@ static constexpr uint32_t kRoutedMarker = 0xfffffffdu;  // in out_len[b]: "compr
 // kFast: with the fast dense path (compressible data).  The single kernel's instance for launches that
 // a sample found incompressible is built without it: its presence alone costs that instance 2 % (register
 // allocation of the strided path), and such blocks do not use it.
-template <int kBlkChunks, bool kLean, typename Tab, bool kRoute = false, bool kFast = true>
+template <int kBlkChunks, bool kLean, typename Tab, bool kRoute = false, bool kFast = true,
+          int kMatchPieces = SZ_MATCH_PIECES>
 __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uint8_t *__restrict__ in,
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
                                                        uint32_t lane)
@@ -603,6 +650,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 uint64_t Vacc = 0, Hpacc = 0;
                 bool acc_open = false;
                 uint32_t acc_emit = next_emit;
+                uint32_t carry = 0;  // lane j: byte acc_emit + j of an open literal that began in the tile before
                 // where the parse stands when a tile is left / entered
                 uint32_t P2 = P, sc2 = 0, long_lane = 64;
                 uint32_t chain2 = 1, pm1_done = 0, quit = 0;
@@ -650,6 +698,20 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 };
 
                 PROF_LAP(14);
+                auto enter_head = [&](uint32_t P2v, uint32_t e2v) {  // bytes, hashes, lookups, candidate loads of P2v's tile
+                    head(P2v >> 6);
+                    if (chain2 && !pm1_done) {  // the reference inserts P-1 before it looks P up
+                        if (e2v >= 1) {
+                            if (lane == e2v - 1)
+                                tab.put(nh, P2v - 1);
+                        } else if (lane == 0) {
+                            tab.put((ld32(in + P2v - 1) * kHashMul) >> shift, P2v - 1);
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                    ncand = tab.get(nh);
+                    head_loads();
+                };
                 for (;;) {  // ================================================ one tile per trip
                     // ---- (A) the elements closed inside the tile that is being left (all its visits)
                     MARK("flush");
@@ -661,11 +723,16 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             // a literal was open when the accumulation began: it ends at the first hit.  It
                             // began at a failed chain probe of this path and ends within the 32 probes a scan
                             // makes here: one tag byte, at most 33 bytes
+                            // (its bytes come out of registers -- those of the tile before were put aside when
+                            // this tile was entered --: a load here would stall the wave on everything in flight)
                             const uint32_t len = (t << 6) + jfirst - acc_emit;
+                            const uint32_t nprev = (t << 6) - acc_emit;
+                            const uint32_t cur = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane - nprev) << 2), (int)a0);
+                            const uint32_t lbyte = lane < nprev ? carry : cur;
                             if (lane == 0)
                                 out[op] = (uint8_t)((len - 1) << 2);
                             if (lane < len)
-                                out[op + 1 + lane] = in[acc_emit + lane];
+                                out[op + 1 + lane] = (uint8_t)lbyte;
                             UNIFORM_JOIN();
                             poisoned = poisoned || len > 60;
                             op += 1 + len;
@@ -700,7 +767,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     PROF_LAP(21);
                     if (long_lane < 64) {  // the last hit's match runs past its 32 local bytes: finish it
                         const uint32_t ip = (t << 6) + long_lane, cnd = lane_get(tcand, long_lane);
-                        const uint32_t m = match_length(in, cnd, ip, n, lane, 32);
+                        PROF_LAPV(26);
+                        const uint32_t m = match_length<kMatchPieces>(in, cnd, ip, n, lane, 32);
+                        PROF_LAPV(27);
                         op = emit_copy(out, op, ip - cnd, m, lane);
                         P2 = ip + m;
                         next_emit = P2;
@@ -739,18 +808,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             UNIFORM_JOIN();
                         }
                     } else {
-                        head(t2);
-                        if (chain2 && !pm1_done) {  // the reference inserts P-1 before it looks P up
-                            if (e2 >= 1) {
-                                if (lane == e2 - 1)
-                                    tab.put(nh, P2 - 1);
-                            } else if (lane == 0) {
-                                tab.put((ld32(in + P2 - 1) * kHashMul) >> shift, P2 - 1);
-                            }
-                            asm volatile("" ::: "memory");
-                        }
-                        ncand = tab.get(nh);
-                        head_loads();
+                        enter_head(P2, e2);
                     }
                     PROF_LAP(20);
                     MARK("compare");
@@ -758,6 +816,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         const uint32_t ml = matchlen32(na, na2, nc, nc2);
                         Hraw = ballot64(nc.x == na.x);
                         tmlw = ml == 32 ? 64u : ml;
+                        // an open literal comes along (then tn == t + 1): its bytes so far are a0 bytes of the tile being left
+                        carry = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((next_emit - (t << 6) + lane) << 2), (int)a0) & 0xffu;
                         a0 = na.x;
                         th = nh;
                         tcand = ncand;
@@ -1228,7 +1288,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
 
                 if (long_lane < 64) {  // the last hit's match runs past the local window: finish it
                     const uint32_t ip = W0 + long_lane, cnd = lane_get(cand, long_lane);
-                    const uint32_t m = match_length(in, cnd, ip, n, lane, lane_get(mcap, long_lane));
+                    const uint32_t m = match_length<kMatchPieces>(in, cnd, ip, n, lane, lane_get(mcap, long_lane));
                     op = emit_copy(out, op, ip - cnd, m, lane);
                     P = ip + m;
                     chain = true;
@@ -1319,9 +1379,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             if (have_win) {
                 m = lane_get(matchlen16(a.y, a.z, a.w, c.y, c.z, c.w), f);
                 if (m == 16)
-                    m = match_length(in, cnd, ip, n, lane, 16);
+                    m = match_length<kMatchPieces>(in, cnd, ip, n, lane, 16);
             } else {
-                m = match_length(in, cnd, ip, n, lane, 4);
+                m = match_length<kMatchPieces>(in, cnd, ip, n, lane, 4);
             }
             // (a7) pending literal, (a6) the copy; then the copy chain continues in a dense window
             emit_lit(next_emit, ip - next_emit);
@@ -1531,6 +1591,11 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
             dup_bm[(wave - 1) * 512u + i] = 0;
     const uint32_t my_slot = blockIdx.x * (kGroupWaves - 1) + (wave ? wave - 1 : 0);
     uint16_t *my_glob = scratch_tables + (size_t)my_slot * kMaxTable;
+    // The waves whose table is in LDS go first at the issue port: they wait least (no table access
+    // leaves the CU), so every slot they take is used; the others spend most of their time waiting
+    // for their table in the L2 anyway (measured: text +2.7 %, low-entropy +2.4 %, mix unchanged).
+    if (wave == 0)
+        __builtin_amdgcn_s_setprio(SZ_LDS_WAVE_PRIO);
     for (;;) {
         // One queue for the whole grid: faster waves take more blocks.  The counter's address goes
         // through VGPRs on purpose: experimental builds of this kernel that hung had `select` spilled
@@ -1588,7 +1653,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
     if (b >= n_blocks)
         return;
     const HashTab<true> tab{dyn_tab, nullptr, nullptr};
-    const uint32_t op = compress_one_block<0, true>(tab, src + (uint64_t)b * block_bytes, block_bytes,
+    // (1 KiB steps of match extension: the blocks are small and the kernel runs four waves per SIMD)
+    const uint32_t op = compress_one_block<0, true, HashTab<true>, false, true, 1>(tab, src + (uint64_t)b * block_bytes, block_bytes,
                                                     dst + (uint64_t)b * dst_stride, flags, lane);
     out_len[b] = op;  // (a9) every lane, same address, same value
 }

@@ -26,16 +26,17 @@ int main(int argc, char **argv)
     hipMalloc(&sc.select, 64); hipMemset(sc.select, 0, 64);
     const char *names[32] = {"window load+hash", "table lookup issue", "cand loads+compare", "walk+commit+verify", "emit", "long match",
                              "strided batch", "strided hit", "walk (per pass)", "commit+readback (per pass)", "lim", "cut windows", "hits/window", "advance/window",
-                             "F: enter (since last lap)", "F: visit top + walk prep", "F: walk loop", "F: exit + commit", "F: next/long (vm drained)", "F: visit end",
-                             "F: spec head / validate", "F: flush", "F: compare (vm drained)", "F: same-tile validate", "F: stale patch after adopt", "F: fresh head+adopt", "", "", "", "", "", ""};
+                             "F: enter (since last lap)", "F: visit top + walk prep", "F: walk loop", "F: exit + commit", "F: long: copy elements (vm drained)", "-",
+                             "F: enter tile: validate/head", "F: flush", "F: compare (vm drained)", "F: same-tile validate", "F: stale patch after adopt", "F: spec head",
+                             "F: long: drain before", "F: long: match_length", "", "", "", ""};
     for (int rep = 0; rep < 2; rep++) {
-        unsigned long long z[128] = {0};
+        unsigned long long z[160] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(szk::g_prof), z, sizeof z);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0);
         szk::launch_compress_blocks(d_in, 65536, nullptr, nb, d_out, 76544, d_len, 1, &sc, 0);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        unsigned long long p[128];
+        unsigned long long p[160];
         hipMemcpyFromSymbol(p, HIP_SYMBOL(szk::g_prof), sizeof p);
         if (rep == 1) {
             printf("nb=%u kernel %.3f ms  %.1f GB/s\n", nb, ms, nb * 65536.0 / ms / 1e6);
@@ -43,12 +44,17 @@ int main(int argc, char **argv)
                 const unsigned long long *q = p + 64 * t;
                 unsigned long long tot = 0;
                 for (int i = 0; i < 10; i++) tot += q[i];
-                for (int i = 14; i < 26; i++) tot += q[i];
+                for (int i = 14; i < 28; i++) tot += q[i];
                 printf("--- %s waves: %llu windows + %llu tiles (%llu visits), %.0f ticks in all\n", t ? "GLOBAL-table" : "LDS-table", q[32 + 3], q[32 + 21], q[32 + 15], (double)tot);
                 for (int i = 0; i < 32; i++)
                     if (q[32 + i])
-                        printf("  %-28s total %12llu  count %9llu  avg %8.2f  (%4.1f%%)\n", names[i], q[i], q[32 + i], (double)q[i] / q[32 + i], (i < 10 || (i >= 14 && i < 26)) ? 100.0 * q[i] / tot : 0.0);
+                        printf("  %-28s total %12llu  count %9llu  avg %8.2f  (%4.1f%%)\n", names[i], q[i], q[32 + i], (double)q[i] / q[32 + i], (i < 10 || (i >= 14 && i < 28)) ? 100.0 * q[i] / tot : 0.0);
             }
+            const char *ml[4] = {"first <= 64 bytes", "whole step, all equal", "whole step with the difference", "last step (masked) + final bytes"};
+            printf("--- match_length, all waves (each lap drains vmcnt)\n");
+            for (int i = 0; i < 4; i++)
+                if (p[144 + i])
+                    printf("  %-34s total %12llu  count %9llu  avg %8.2f\n", ml[i], p[128 + i], p[144 + i], (double)p[128 + i] / p[144 + i]);
         }
     }
     return 0;
