@@ -206,3 +206,40 @@ def test_ten_thousand_small_blocks_every_one_against_the_oracle():
         dst, ol = P.compress_blocks(src, bs, nb, dst_stride=stride)
         torch.cuda.synchronize()
         parity_util.assert_all_blocks_match_oracle(src, dst, ol, nb, stride, what="%s pages of %d" % (kind, bs), block=bs)
+
+
+def test_long_matches_of_every_length_class_offset_and_alignment():
+    """The long match extension works in steps (first bytes up to a 16-byte boundary of the input,
+    whole 4 KiB steps, a masked last step, the final < 16 bytes): blocks of random bytes with ONE
+    planted repeat of length L at distance d, started at every alignment class and ended by a
+    differing byte or by the block end, against the oracle."""
+    rng = np.random.default_rng(20261004)
+    blocks, names = [], []
+    lengths = [33, 47, 48, 49, 63, 64, 65, 80, 81, 95, 96, 97, 111, 112, 113, 1023, 1024, 1025, 1100, 4095, 4096,
+               4097, 4111, 4112, 4113, 4160, 4200, 8191, 8192, 8208, 8209, 12000, 20000]
+    dists = [1, 2, 3, 5, 15, 16, 17, 64, 100, 4096, 4099, 20000]
+    k = 0
+    for L in lengths:
+        for d in dists:
+            start = 20001 + (k % 16)  # the copy starts at every residue mod 16 over the cases
+            k += 1
+            n = 65536
+            b = rng.integers(0, 256, n, dtype=np.uint8)
+            for i in range(L):  # (a repeat at distance d < L overlaps itself, as in a run)
+                b[start + i] = b[start + i - d]
+            if start + L < n:
+                b[start + L] = b[start + L - d] ^ 0x5A
+            blocks.append(b.tobytes())
+            names.append(("stop", L, d, start))
+    for d in dists:  # ... and repeats that run into the block end, for every length of the last partial step
+        for tail in (0, 1, 15, 16, 17, 31, 100, 1023, 1024, 1025, 4095):
+            n = 65536 - tail
+            start = 30000 + (d % 7)
+            b = rng.integers(0, 256, n, dtype=np.uint8)
+            for i in range(start, n):
+                b[i] = b[i - d]
+            blocks.append(b.tobytes())
+            names.append(("to-end", n, d, start))
+    got = compress_many(blocks)
+    for g, b, nm in zip(got, blocks, names):
+        _assert_same(g, oracle_lib.raw_compress(b), str(nm))
