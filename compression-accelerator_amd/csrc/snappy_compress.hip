@@ -13,8 +13,9 @@
 //     consecutive bytes ("dense window", scalar walk over the ballot mask, prefix-sum packing of
 //     the elements) or the next 64 probes of the skip schedule ("strided batch") -- and the table
 //     ends up exactly as the serial parse leaves it;
-//   * long matches extend 64 B, then 1 KiB per step with a ballot; literal bytes and split copy
-//     elements are written by all lanes; incompressible blocks stream through the register file.
+//   * long matches extend up to a 16-byte boundary of the input, then 4 KiB of both strings per step
+//     (one OR-reduction and one ballot); literal bytes and split copy elements are written by all
+//     lanes; incompressible blocks stream through the register file.
 //
 // No MFMA: this is byte/integer work bounded by HBM ("Roofline").
 #include <hip/hip_runtime.h>
