@@ -780,11 +780,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         long_lane = 64;
                         PROF_LAPV(18);
                     }
-                    if (quit || poisoned)
-                        break;
-                    // ---- (B) enter the tile of P2
+                    // ---- (B) enter the tile of P2 -- or leave: the block's tail, a state handed back (quit: P2,
+                    // chain2, sc2 are that state), a poisoned block (one way out: every exit of its own costs copies)
                     MARK("enter");
-                    if (P2 + kFastMargin > ip_limit) {
+                    if ((quit != 0) | poisoned | (P2 + kFastMargin > ip_limit)) {
                         P = P2;
                         chain = chain2 != 0;
                         sc = sc2;
@@ -867,10 +866,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         const uint64_t far = ballot64(dist >= run32) & ~below63(e);
                         const uint32_t lead = ctz64(Hm | (1ull << 63)) - e;
                         const uint32_t lead_bad = (c_in ^ 1u) & (sc_in + lead > 31 ? 1u : 0u);
-                        if ((far != 0) | (lead_bad != 0)) {
-                            P = base + e;
-                            chain = c_in != 0;
-                            sc = sc_in;
+                        if ((far != 0) | (lead_bad != 0)) {  // (P2, chain2, sc2 are this very state: base + e, c_in, sc_in)
                             hold_fast = true;
                             quit = 1;
                             break;
@@ -966,18 +962,14 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                 UNIFORM_JOIN();
                             }
                         }
-                        if (poisoned)
-                            break;
                         PROF_LAP(17);
                         MARK("after_commit");
                         next_emit = emit2;
                         Vacc |= V;
                         Hpacc |= Hp;
-                        if (ll < 64) {
-                            long_lane = ll;
-                            break;
-                        }
-                        if ((P2 >> 6) != t)
+                        long_lane = ll;  // (64: none)
+                        // (one way out of the visits of a tile: every exit of its own costs a set of copies)
+                        if (poisoned | (ll < 64) | ((P2 >> 6) != t))
                             break;
                         // the same tile again (after a cut): insert P-1, then give the lanes whose bucket
                         // was written since their lookup the new candidate
