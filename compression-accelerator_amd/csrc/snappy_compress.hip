@@ -684,18 +684,21 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 auto patch = [&](uint64_t sel, uint32_t cnow) {
                     const bool on = __builtin_amdgcn_inverse_ballot_w64(sel);
                     const uint32_t pos = (t << 6) + lane;
-                    u32x4 x = {0, 0, 0, 0}, x2 = {0, 0, 0, 0}, c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
-                    if (on) {
+                    bool hit = false;
+                    if (on) {  // (everything inside: nothing to initialise for the other lanes)
                         tcand = cnow;
-                        x = ld128(in + pos);
-                        x2 = ld128(in + pos + 16);
-                        c = ld128(in + cnow);
-                        c2 = ld128(in + cnow + 16);
+                        u32x4 x = na, x2 = na2;  // the lanes' own bytes: still those of the head unless a next head was issued
+                        if (kSpec) {
+                            x = ld128(in + pos);
+                            x2 = ld128(in + pos + 16);
+                        }
+                        const u32x4 c = ld128(in + cnow), c2 = ld128(in + cnow + 16);
+                        const uint32_t ml = matchlen32(x, x2, c, c2);
+                        tmlw = ml == 32 ? 64u : ml;
+                        hit = c.x == x.x;
                     }
-                    const uint32_t ml = matchlen32(x, x2, c, c2);
-                    Hraw = (Hraw & ~sel) | ballot64(on && c.x == x.x);
-                    tmlw = on ? (ml == 32 ? 64u : ml) : tmlw;
                     UNIFORM_JOIN();
+                    Hraw = (Hraw & ~sel) | ballot64(on && hit);
                 };
 
                 PROF_LAP(14);
