@@ -719,7 +719,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 for (;;) {  // ================================================ one tile per trip
                     // ---- (A) the elements closed inside the tile that is being left (all its visits)
                     MARK("flush");
-                    if (Hpacc != 0) {
+                    if (__builtin_expect(Hpacc != 0, 1)) {
                         const uint32_t jfirst = ctz64(Hpacc);
                         const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hpacc);
                         uint64_t Lit = Vacc & ~Hpacc & below63(jlast);
@@ -769,7 +769,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         op += lane_get(incl, 63);
                     }
                     PROF_LAP(21);
-                    if (long_lane < 64) {  // the last hit's match runs past its 32 local bytes: finish it
+                    if (__builtin_expect(long_lane < 64, 0)) {  // the last hit's match runs past its 32 local bytes: finish it
                         const uint32_t ip = (t << 6) + long_lane, cnd = lane_get(tcand, long_lane);
                         PROF_LAPV(26);
                         const uint32_t m = match_length<kMatchPieces>(in, cnd, ip, n, lane, 32);
@@ -786,7 +786,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     // ---- (B) enter the tile of P2 -- or leave: the block's tail, a state handed back (quit: P2,
                     // chain2, sc2 are that state), a poisoned block (one way out: every exit of its own costs copies)
                     MARK("enter");
-                    if ((quit != 0) | poisoned | (P2 + kFastMargin > ip_limit)) {
+                    if (__builtin_expect((quit != 0) | poisoned | (P2 + kFastMargin > ip_limit), 0)) {
                         P = P2;
                         chain = chain2 != 0;
                         sc = sc2;
@@ -869,7 +869,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         const uint64_t far = ballot64(dist >= run32) & ~below63(e);
                         const uint32_t lead = ctz64(Hm | (1ull << 63)) - e;
                         const uint32_t lead_bad = (c_in ^ 1u) & (sc_in + lead > 31 ? 1u : 0u);
-                        if ((far != 0) | (lead_bad != 0)) {  // (P2, chain2, sc2 are this very state: base + e, c_in, sc_in)
+                        if (__builtin_expect((far != 0) | (lead_bad != 0), 0)) {  // (P2, chain2, sc2 are this very state: base + e, c_in, sc_in)
                             hold_fast = true;
                             quit = 1;
                             break;
@@ -936,7 +936,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                     __hip_atomic_store(tab.bm + (th >> 5), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                                 L = ballot64(inC && (old & bit) != 0);
                             }
-                            if (L != 0) {  // two inserted lanes share a bucket: end the visit before the second one
+                            if (__builtin_expect(L != 0, 0)) {  // two inserted lanes share a bucket: end the visit before the second one
                                 if constexpr (Tab::kInLds) {
                                     asm volatile("" ::: "memory");
                                     if (inC)
@@ -972,7 +972,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         Hpacc |= Hp;
                         long_lane = ll;  // (64: none)
                         // (one way out of the visits of a tile: every exit of its own costs a set of copies)
-                        if (poisoned | (ll < 64) | ((P2 >> 6) != t))
+                        if (__builtin_expect(poisoned | (ll < 64) | ((P2 >> 6) != t), 1))
                             break;
                         // the same tile again (after a cut): insert P-1, then give the lanes whose bucket
                         // was written since their lookup the new candidate
