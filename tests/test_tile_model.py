@@ -37,3 +37,30 @@ def test_sizes_around_the_margins():
     src = fuzzgen.gen("words", 9, 70000).tobytes()
     for n in (0, 1, 14, 15, 16, 100, 127, 128, 129, 143, 144, 160, 191, 192, 193, 255, 256, 257, 300, 1000, 4095, 4096, 4097):
         _check(src[:n])
+
+
+# ---- the extension prepared for a later round ("sparse scans inside the tile path"): the
+# first segment of a visit follows the scan's schedule past its 32nd probe (lanes the scan skips are
+# neither looked at nor inserted), later segments that would do so end the visit, and the tile path is
+# entered in scans as well as at the end of copies.  Same bytes as the oracle; the kernel does not use it yet.
+def _check_sparse(data):
+    st = {}
+    assert tile_model.compress_fragment(data, stats=st, sparse=True) == oracle_lib.compress_fragment(data)
+    return st
+
+
+def test_sparse_scans_in_the_tile_path_corpora():
+    mtg = fuzzgen.corpus("mtg")
+    st = _check_sparse(mtg[:65536])
+    assert st.get("flagged", 0) == 0 and st["far_cuts"] > 0  # nothing handed back, and the cut in front of a sparse segment is taken
+    st = _check_sparse(mtg[:4096] * 16)
+    assert st.get("flagged", 0) == 0
+    _check_sparse(fuzzgen.corpus("fox"))
+    st = _check_sparse(fuzzgen.tiled_block(fuzzgen.corpus("random_ascii"), 3))
+    assert st["flagged"] > 0  # steps past half a tile: the general code
+
+
+@pytest.mark.parametrize("kind", fuzzgen.KINDS)
+def test_sparse_scans_in_the_tile_path_generators(kind):
+    for seed, n in ((1, 300), (2, 5000), (3, 20000), (4, 65536), (8, 65521)):
+        _check_sparse(fuzzgen.gen(kind, seed, n).tobytes())

@@ -16,6 +16,19 @@ def ld32(d, p):
     return d[p] | (d[p + 1] << 8) | (d[p + 2] << 16) | (d[p + 3] << 24)
 
 
+def _probe_offsets(n=448):
+    off, skip, pos = [], 32, 0
+    for _ in range(n):
+        off.append(pos)
+        step = skip >> 5
+        skip += step
+        pos += step
+    return off
+
+
+OFF = _probe_offsets()  # distance of the k-th probe of a scan from its first one (skip_k = 32 + OFF[k])
+
+
 def below(k):  # bits 0..k-1, k in 0..64
     return (1 << k) - 1
 
@@ -29,7 +42,8 @@ def top(x):  # index of the highest set bit
 
 
 class Model:
-    def __init__(self, data, fast=True, margin=128, stats=None):
+    def __init__(self, data, fast=True, margin=128, stats=None, sparse=False):
+        self.sparse = sparse  # scans past their 32nd probe stay in the tile path (first segment of a visit)
         self.d = bytes(data)
         self.n = len(self.d)
         self.out = bytearray()
@@ -96,11 +110,11 @@ class Model:
         P, chain, skip = 1, False, 32
         hold = False  # the fast path declined this state (a scan may reach probe 32): one serial step first
         while True:
-            if chain and self.fast and not hold and P + self.margin <= self.ip_limit:
-                P0 = P
-                P, chain, sc = self.fast_path(P)
-                skip = 32 + sc
-                hold = P == P0 and chain
+            if (chain or self.sparse) and self.fast and not hold and P + self.margin <= self.ip_limit:
+                P0, c0, s0 = P, chain, (skip - 32 if chain else None)
+                P, chain, sc = self.fast_path(P, chain, 0 if chain else self.sc_of_skip(skip))
+                skip = 32 + OFF[sc]
+                hold = P == P0
                 continue
             hold = False
             if chain:
@@ -161,34 +175,57 @@ class Model:
                 m += 1
             ml[l] = m
 
-    def fast_path(self, P):
+    @staticmethod
+    def sc_of_skip(skip):  # probe index of a scan whose skip counter stands at `skip`
+        return OFF.index(skip - 32)
+
+    def fast_path(self, P, chain=True, sc=0):
         """Entered with chain == True at P.  Returns (P, chain, sc) for the serial code, or
         (None, ..) never (the tail is always left to the serial code)."""
         st = self.stats
         d, tab = self.d, self.tab
         t, e = P >> 6, P & 63
-        c_in, sc_in = True, 0
-        # the reference inserts P-1 before it looks P up
-        tab[self.H(P - 1)] = P - 1
+        c_in, sc_in = chain, sc
+        if chain:  # the reference inserts P-1 before it looks P up
+            tab[self.H(P - 1)] = P - 1
         h, cand, Hraw, ml = self.stage(t)
         Vacc = Hpacc = 0
-        acc_open, acc_emit = False, self.next_emit
+        acc_open, acc_emit = (not chain), self.next_emit
         while True:
             st["visits"] = st.get("visits", 0) + 1
             Hm = Hraw & ~below(e) & M64
-            # ---- slow-path conditions: a scan could reach probe 32 inside this tile
-            flagged = False
-            for l in range(e, 33):
-                tl = Hm >> l
-                if tl == 0 or ctz(tl) >= 32:
+            A = M64  # lanes of the first segment that are probed (sparse mode: a pattern past probe 32)
+            A_scan, sc0, nxt_pos, nxt_k, h1 = 0, 0, 64, 0, None
+            if not self.sparse:
+                # ---- slow-path conditions: a scan could reach probe 32 inside this tile
+                flagged = False
+                for l in range(e, 33):
+                    tl = Hm >> l
+                    if tl == 0 or ctz(tl) >= 32:
+                        flagged = True
+                lead = (ctz(Hm) if Hm else 64) - e
+                if not c_in and sc_in + lead > 31:
                     flagged = True
-            lead = (ctz(Hm) if Hm else 64) - e
-            if not c_in and sc_in + lead > 31:
-                flagged = True
-            if flagged:
-                st["flagged"] = st.get("flagged", 0) + 1
-                self.flush(t, Vacc, Hpacc, acc_open, acc_emit, cand, ml, 64)
-                return 64 * t + e, c_in, sc_in
+                if flagged:
+                    st["flagged"] = st.get("flagged", 0) + 1
+                    self.flush(t, Vacc, Hpacc, acc_open, acc_emit, cand, ml, 64)
+                    return 64 * t + e, c_in, sc_in
+            else:
+                # ---- the probes of the first segment: the chain probe at e (c_in), then the scan's schedule
+                sc0 = 0 if c_in else sc_in
+                pos, k = (e + 1, 0) if c_in else (e, sc_in)
+                if (32 + OFF[k]) >> 5 > 32:  # (a scan whose steps have grown past half a tile: the general code)
+                    st["flagged"] = st.get("flagged", 0) + 1
+                    self.flush(t, Vacc, Hpacc, acc_open, acc_emit, cand, ml, 64)
+                    return 64 * t + e, c_in, sc_in
+                while pos < 64:
+                    A_scan |= 1 << pos
+                    pos += (32 + OFF[k]) >> 5
+                    k += 1
+                nxt_pos, nxt_k = pos, k
+                A = A_scan | ((1 << e) if c_in else 0)
+                H1 = Hm & A
+                h1 = ctz(H1) if H1 else None
             # ---- walk: vJ[l] = where the parse goes from lane l (next hit at or after l, then past its match)
             vJ = [64] * 64
             for l in range(64):
@@ -197,11 +234,29 @@ class Model:
                     nh = l + ctz(tl)
                     mw = 64 if ml[nh] == 32 else ml[nh]
                     vJ[l] = min(nh + mw, 64)
-            S, jj = 0, e
-            while jj < 64:
-                S |= 1 << jj
-                jj = vJ[jj]
             lim = 64
+            seg1 = 0  # lanes of the first segment up to and including its hit (sparse mode)
+            if not self.sparse:
+                S, jj = 0, e
+                while jj < 64:
+                    S |= 1 << jj
+                    jj = vJ[jj]
+            else:
+                S = 1 << e
+                if h1 is None:
+                    seg1 = M64 & ~below(e)
+                else:
+                    seg1 = below(h1 + 1) & ~below(e)
+                    jj = min(h1 + (64 if ml[h1] == 32 else ml[h1]), 64)
+                    while jj < 64:
+                        tl = Hm >> jj
+                        if jj <= 32 and (tl == 0 or ctz(tl) >= 32):  # this segment would leave the dense regime inside the tile:
+                            lim = jj                                  # the visit ends here; it becomes a first segment
+                            st["far_cuts"] = st.get("far_cuts", 0) + 1
+                            break
+                        S |= 1 << jj
+                        jj = vJ[jj]
+                Hm = Hm & (~seg1 | ((1 << h1) if h1 is not None else 0)) & M64  # hits at lanes the scan skips do not exist
             # ---- exit state for limit `lim`, commit, conflict check; at most one repeat with lim = cut
             for attempt in range(2):
                 bl = below(lim)
@@ -216,7 +271,13 @@ class Model:
                     bitlim = (1 << lim) if lim < 64 else 0
                     V = (((Hp << 1) | bitlim) - Sx) & M64 & bl
                     chain2, P2 = False, 64 * t + lim
-                    if Sx == (1 << e) and not c_in:
+                    if self.sparse and Sx == (1 << e):  # still in the first segment: its schedule says where it stands
+                        rest = A_scan & ~bl & M64
+                        P2 = 64 * t + (ctz(rest) if rest else nxt_pos)
+                        sc2 = sc0 + bin(A_scan & bl).count("1")
+                        if c_in:
+                            new_emit = 64 * t + e
+                    elif Sx == (1 << e) and not c_in:
                         sc2 = sc_in + lim - e
                     else:
                         new_emit = 64 * t + s_l
@@ -237,7 +298,7 @@ class Model:
                 if pm1_done:  # the copy ends with the tile: its last byte is P-1 of the next tile's first probe
                     Ins |= 1 << 63
                 assert V & Ins == 0
-                C = V | Ins
+                C = (V & (A | ~seg1) & M64) | Ins  # (sparse mode: lanes the first segment's scan skips are not inserted)
                 # conflict: two lanes of C share a bucket -> the later one should have seen the earlier
                 seen, cut = {}, 64
                 for l in range(64):
@@ -318,5 +379,5 @@ class Model:
                 self.copy64(p - cand[l], ml[l])
 
 
-def compress_fragment(data, fast=True, stats=None):
-    return Model(data, fast=fast, stats=stats).compress()
+def compress_fragment(data, fast=True, stats=None, sparse=False):
+    return Model(data, fast=fast, stats=stats, sparse=sparse).compress()
