@@ -22,7 +22,6 @@ Every block of every pass is compared with the oracle after the timed region.
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -50,28 +49,40 @@ def parse_args(argv=None):
 
 # ------------------------------------------------------------------------- launcher (no GPU call)
 
-def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def launch_ranks(n, script, script_args, env=None, timeout=None):
     """Starts n ranks of `script` under torch.distributed.run on this node as a child process (never
     an exec: a process that has initialised the GPU must not be replaced, and this one stays clean
-    anyway), relays the child's stdout/stderr and returns (exit code, the last JSON line printed)."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(script_args)
+    anyway), relays the child's stdout/stderr and returns (exit code, the last JSON line printed).
+    The rendezvous is torchrun's own (`--standalone`: a port it binds itself, nothing probed and
+    released here); the child is the leader of a new session, so that on a timeout or an error the
+    whole group -- the launcher AND its ranks -- is killed and no rank keeps a GPU."""
+    import signal
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+           "--nnodes=1", "--nproc-per-node", str(n), script] + list(script_args)
     e = dict(os.environ if env is None else env)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this pool)
-    p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)  # (a launcher started from inside a rank must not hand its own identity down)
+    p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except BaseException:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)  # the session's process group: launcher and ranks
+        except ProcessLookupError:
+            pass
+        p.wait()
+        raise
+    if p.returncode != 0:  # a failed rank: torchrun has stopped the others; make sure of it
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
     line = None
-    for ln in p.stdout.splitlines():
+    for ln in out.splitlines():
         if ln.startswith("{") and ln.rstrip().endswith("}"):
             line = ln
-    return p.returncode, line, p.stdout, p.stderr
+    return p.returncode, line, out, err
 
 
 def layout_fields(gathered, offsets, local_lens, rank, blocks_per_rank):
@@ -273,6 +284,7 @@ def cpu_baseline(kind, sample_blocks, budget_s=10.0):
         res[threads] = (sample_blocks * BLOCK * reps / sec / 1e9, reps)
     out = {"value": round(res[cores][0], 3), "unit": "GB/s", "cores": cores, "kind": "port",
            "single_thread_GBps": round(res[1][0], 3), "passes": {"1_thread": res[1][1], "%d_threads" % cores: res[cores][1]},
+           "fewer_than_20_passes": min(res[1][1], res[cores][1]) < 20,
            "host": host_cpu(),
            "sample": "%d x 64 KiB blocks of workload %s, oracle/snappy_oracle.c, %d pinned pthreads, preallocated buffers, "
                      "1 warm-up + timed passes" % (sample_blocks, kind, cores)}

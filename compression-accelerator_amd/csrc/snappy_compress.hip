@@ -48,6 +48,16 @@ namespace szk {
 #define MARK(name) do { } while (0)
 #endif
 
+// Diagnostic build only (tools/teamtrace.hip, -DSZ_TRACE): time line of the team kernel's turns.  The waves of
+// the first blocks store (s_memtime << 28 | turn << 4 | phase) at the phase boundaries of every turn.
+#ifdef SZ_TRACE
+__device__ unsigned long long *g_trace;  // [traced blocks][waves][kTraceCap]
+static constexpr uint32_t kTraceCap = 16384, kTraceBlocks = 8;
+#define TRACE(id) do { if (team.trace && trn_ < kTraceCap) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); team.trace[trn_++] = (t_ << 28) | ((unsigned long long)(myturn & 0xffffffu) << 4) | (id); } } while (0)
+#else
+#define TRACE(id) do { } while (0)
+#endif
+
 #ifdef SZ_PROF
 __device__ unsigned long long g_prof[160];  // [128,160): phases of match_length (16 sums, 16 counts), all waves
 #define ML_START() unsigned long long mlt_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mlt_) :: "memory")
@@ -403,6 +413,76 @@ struct HashTab {
     }
 };
 
+// ------------------------------------------------------------------------ wave teams
+//
+// TEAM KERNEL (round 3): kWaves wavefronts of one workgroup compress ONE block together and share ONE hash
+// table in LDS -- no table leaves the CU.  The greedy parse is serial, so what the waves share is a
+// pipeline, not the data: the parse state travels from wave to wave as a TOKEN (one 64-bit LDS word:
+// position, chain flag, scan index, pending literal start, turn number) and each wave in turn runs the
+// serial part of one tile (stale check of its lookups, walk, table commit).  Everything else a tile costs --
+// the element writer of the tile it has just parsed and the head of its next tile (bytes, hashes, table
+// lookups, candidate loads, compares) -- runs while the other waves hold the token.  Lookups made ahead of
+// the token are speculative: they are re-read from the table once the token arrives, and only the lanes
+// whose bucket was written in between get their candidate again (same rule as the single-wave kSpec path;
+// tests/tile_model.py).  The output position travels on a second token behind the first (a writer needs to
+// know where the elements of the tile before end, nothing else).
+struct NoTeam {
+    static constexpr int kWaves = 1;
+};
+template <int W>
+struct WaveTeam {
+    static constexpr int kWaves = W;
+    uint64_t *ptok;  // LDS: parse token
+    uint64_t *otok;  // LDS: output-position token
+    uint32_t wave;   // this wave's place in the team (0 starts every block)
+    unsigned long long *trace;  // (-DSZ_TRACE builds: this wave's stamps for this block, or null)
+};
+static constexpr uint32_t kTeamDoneTurn = 0x3fffffu;  // turn field of a token: the block is finished
+static constexpr uint32_t kTeamNotMine = 0xfffffffcu; // return value of the waves that did not finish the block
+#ifndef SZ_TEAM_SPIN_CAP
+#define SZ_TEAM_SPIN_CAP (1u << 24)  // polls before a waiting wave gives the block up (seconds: only a lost wave gets there)
+#endif
+#ifndef SZ_TEAM_PRIO
+#define SZ_TEAM_PRIO 2  // issue priority of the wave that holds the parse token
+#endif
+
+__device__ __forceinline__ uint64_t team_pack_parse(uint32_t turn, uint32_t P2, uint32_t chain2, uint32_t sc2,
+                                                    uint32_t pm1, uint32_t next_emit)
+{
+    return (uint64_t)(P2 | (chain2 << 17) | (sc2 << 18) | (pm1 << 24)) | ((uint64_t)next_emit << 25) |
+           ((uint64_t)turn << 42);
+}
+// every lane stores the same value to the same address (one LDS write); the table commits of this wave are
+// ahead of it in the LDS queue and the wait makes that explicit
+__device__ __forceinline__ void team_publish(uint64_t *slot, uint64_t v)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef SZ_TEAM_NO_WAKEUP
+    asm volatile("s_wakeup" ::: "memory");
+#endif
+}
+// waits until the token in `slot` carries `turn` (or "done"); returns the token, or 0 with *lost = true
+__device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t turn, bool &lost)
+{
+    uint64_t v = 0;
+    lost = false;
+    for (uint32_t spin = 0;; spin++) {
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        v = ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+        const uint32_t tt = (uint32_t)(v >> 42);
+        if (tt == turn || tt == kTeamDoneTurn)
+            break;
+        if (spin >= SZ_TEAM_SPIN_CAP) {
+            lost = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");  // nothing of what follows is read before the token
+    return v;
+}
+
 // One block by one wavefront.  kChunks = 1 KiB chunks of the block kept in registers.
 // Auto mode routes blocks between the two kernels: the single kernel (kRoute) gives a block up as
 // soon as it has emitted its first copy and marks it for the multi-wave kernel.
@@ -412,17 +492,37 @@ static constexpr uint32_t kRoutedMarker = 0xfffffffdu;  // in out_len[b]: "compr
 // a sample found incompressible is built without it: its presence alone costs that instance 2 % (register
 // allocation of the strided path), and such blocks do not use it.
 template <int kBlkChunks, bool kLean, typename Tab, bool kRoute = false, bool kFast = true,
-          int kMatchPieces = SZ_MATCH_PIECES>
+          int kMatchPieces = SZ_MATCH_PIECES, typename TeamT = NoTeam>
 __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uint8_t *__restrict__ in,
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
-                                                       uint32_t lane)
+                                                       uint32_t lane, const TeamT &team = TeamT{})
 {
+    constexpr int kTeamW = TeamT::kWaves;  // 1: this wave compresses the block alone
+    // team mode: wave 0 starts the block (it holds the parse token of turn 0 and the output position);
+    // the others wait for a token.  Blocks too short for the fast dense path are wave 0's alone.
+    bool holder = true, own_op = true, team_gone = false, team_lost = false;
+    uint32_t myturn = 0;
+#ifdef SZ_TRACE
+    uint32_t trn_ = 0;
+#endif
+    if constexpr (kTeamW > 1) {
+        holder = own_op = team.wave == 0;
+        myturn = team.wave;
+        if (n < 1024 && team.wave != 0)
+            return kTeamNotMine;
+    }
     // (a8) varint32(n), n <= 65536 -> at most 3 bytes.  (`op` is a select of wave-uniform values, not a
     // value merged behind the per-lane `if`: the compiler keeps the whole parse state in scalar
     // registers only while it can prove it uniform -- `opt -passes='print<uniformity>'`.)
     const uint32_t nb = (flags & kFlagBlockVarint) ? (n < 128 ? 1u : (n < 16384 ? 2u : 3u)) : 0u;
-    if (lane < nb)
-        out[lane] = (uint8_t)(((n >> (7 * lane)) & 0x7f) | (lane + 1 < nb ? 0x80 : 0));
+    if constexpr (kTeamW > 1) {
+        if (holder && lane < nb)
+            out[lane] = (uint8_t)(((n >> (7 * lane)) & 0x7f) | (lane + 1 < nb ? 0x80 : 0));
+        UNIFORM_JOIN();
+    } else {
+        if (lane < nb)
+            out[lane] = (uint8_t)(((n >> (7 * lane)) & 0x7f) | (lane + 1 < nb ? 0x80 : 0));
+    }
     uint32_t op = nb;
     if (n == 0)
         return op;
@@ -494,7 +594,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 advance_bufs(k);
             cut_window(W);
         };
-        if (n >= 16) {
+        if (kTeamW > 1 && !holder) {
+            kcur = 0xfffffffeu;  // no buffer yet: the first head of this wave loads its own
+        } else if (n >= 16) {
             wcur = load_buf(0);
             wnxt = fetch_buf(1, wnxt_sh);
         }
@@ -538,7 +640,18 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         while (log2T < 14 && (1u << log2T) < n)
             log2T++;
         const uint32_t shift = 32 - log2T;
-        tab.clear(log2T, lane);
+        if constexpr (kTeamW > 1) {
+            if (n >= 1024) {  // the whole team: a slice each, then every wave sees an empty table
+                const uint32_t nvec = (1u << log2T) >> 3;
+                for (uint32_t i = team.wave * 64u + lane; i < nvec; i += 64u * kTeamW)
+                    reinterpret_cast<u32x4 *>(tab.lds)[i] = u32x4{0, 0, 0, 0};
+                __syncthreads();
+            } else {
+                tab.clear(log2T, lane);
+            }
+        } else {
+            tab.clear(log2T, lane);
+        }
 
         // literal emission; a long block-prefix literal is only accounted for here and stored from
         // the prefetched registers after the main loop (one copy of that code, at a known address)
@@ -616,8 +729,357 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 break;
 #endif
 
+            if constexpr (kTeamW > 1) {
+                // (blocks under 1 KiB are wave 0's alone -- the others have left --: general code only)
+                if (!holder || (n >= 1024 && chain && !hold_fast && P + kFastMargin <= ip_limit)) {
+                    // =============================================== TEAM FAST DENSE PATH (fixed tiles, one TURN per tile)
+                    // Same tiles, visits and masks as the single-wave fast dense path below (tests/tile_model.py);
+                    // what differs is who does what when.  A turn = [token] -> stale check of the lookups made
+                    // ahead -> visits (walk, exit state, table commit) -> [token passed on] -> element writer of
+                    // this tile (waits for the output position of the tile before) -> head of this wave's next
+                    // tile (kTeamW - 1 tiles past the one the next wave takes) -> wait.  A state the fast path does
+                    // not take is kept by the wave that meets it: it runs the general code below (it owns the
+                    // output position then) and comes back here, or ends the block.
+                    first_scan = false;
+                    uint32_t t = 0, e = 0, sc_in = 0, c_in = 1;
+                    uint32_t a0 = 0, th = 0, tcand = 0, tmlw = 0;
+                    uint64_t Hraw = 0;
+                    u32x4 na = {0, 0, 0, 0}, na2 = {0, 0, 0, 0}, nc = {0, 0, 0, 0}, nc2 = {0, 0, 0, 0};
+                    uint32_t nh = 0, ncand = 0, tn = 0;
+                    bool have_spec = false;
+                    uint32_t P2 = P, sc2 = 0, chain2 = 1, pm1_done = 0, quit = 0;
+                    auto head = [&](uint32_t tt) {  // bytes and hashes of tile tt
+                        const uint32_t k = tt >> 1;  // buffer k = bytes [128 k, 128 k + 256) holds the tile + 32
+                        if (k != kcur)
+                            advance_bufs(k);
+                        const uint32_t i0 = ((tt & 1u) << 6) + lane4;
+                        uint32_t d[9];
+#pragma unroll
+                        for (int q = 0; q < 9; q++)
+                            d[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i0 + 4 * q), (int)wcur);
+                        na.x = __builtin_amdgcn_alignbyte(d[1], d[0], lane3);
+                        na.y = __builtin_amdgcn_alignbyte(d[2], d[1], lane3);
+                        na.z = __builtin_amdgcn_alignbyte(d[3], d[2], lane3);
+                        na.w = __builtin_amdgcn_alignbyte(d[4], d[3], lane3);
+                        na2.x = __builtin_amdgcn_alignbyte(d[5], d[4], lane3);
+                        na2.y = __builtin_amdgcn_alignbyte(d[6], d[5], lane3);
+                        na2.z = __builtin_amdgcn_alignbyte(d[7], d[6], lane3);
+                        na2.w = __builtin_amdgcn_alignbyte(d[8], d[7], lane3);
+                        nh = (na.x * kHashMul) >> shift;
+                        tn = tt;
+                    };
+                    auto head_loads = [&]() {
+                        nc = ld128(in + ncand);  // ncand < pos, pos + 32 <= n here
+                        nc2 = ld128(in + ncand + 16);
+                    };
+                    // candidates changed for the lanes in `sel` (their bucket was written after their lookup):
+                    // the candidate's string again, hit bit and match length merged in
+                    auto patch = [&](uint64_t sel, uint32_t cnow) {
+                        const bool on = __builtin_amdgcn_inverse_ballot_w64(sel);
+                        bool hit = false;
+                        if (on) {
+                            tcand = cnow;
+                            const u32x4 c = ld128(in + cnow), c2 = ld128(in + cnow + 16);
+                            const uint32_t ml = matchlen32(na, na2, c, c2);
+                            tmlw = ml == 32 ? 64u : ml;
+                            hit = c.x == na.x;
+                        }
+                        UNIFORM_JOIN();
+                        Hraw = (Hraw & ~sel) | ballot64(on && hit);
+                    };
+                    for (;;) {  // ================================================ one turn per trip
+                        P2 = uni(P2); sc2 = uni(sc2); chain2 = uni(chain2); pm1_done = uni(pm1_done); quit = uni(quit);
+                        holder = unib(holder); own_op = unib(own_op); myturn = uni(myturn); next_emit = uni(next_emit);
+                        op = uni(op); poisoned = unib(poisoned); have_spec = unib(have_spec); tn = uni(tn); kcur = uni(kcur);
+                        TRACE(0);
+                        if (!holder) {
+                            bool lost;
+                            const uint64_t tok = team_wait(team.ptok, myturn, lost);
+                            if (lost || (uint32_t)(tok >> 42) == kTeamDoneTurn) {
+                                team_gone = true;
+                                team_lost = lost;
+                                break;
+                            }
+                            P2 = (uint32_t)tok & 0x1ffffu;
+                            chain2 = ((uint32_t)tok >> 17) & 1u;
+                            sc2 = ((uint32_t)tok >> 18) & 63u;
+                            pm1_done = ((uint32_t)tok >> 24) & 1u;
+                            next_emit = (uint32_t)(tok >> 25) & 0x1ffffu;
+                            holder = true;
+                        }
+                        TRACE(1);
+                        if (SZ_TEAM_PRIO)
+                            __builtin_amdgcn_s_setprio(SZ_TEAM_PRIO);
+                        // ---- enter the tile of P2
+                        const uint32_t t2 = P2 >> 6, e2 = P2 & 63u;
+                        const uint32_t acc_emit = next_emit;   // start of the literal that is open on entry (if any)
+                        const bool acc_open = chain2 == 0;
+                        uint64_t stale = 0;
+                        uint32_t cnow = 0;
+                        if (have_spec && t2 == tn) {
+                            // the head issued ahead is this tile: check its lookups against the table
+                            cnow = tab.get(nh);
+                            stale = ballot64(cnow != ncand);
+                            if (chain2 && !pm1_done) {  // P-1 goes in first: the lanes of its bucket then see it
+                                uint32_t hp;
+                                if (e2 >= 1)
+                                    hp = lane_get(nh, e2 - 1);
+                                else
+                                    hp = uni((ld32(in + P2 - 1) * kHashMul) >> shift);
+                                const uint64_t same = ballot64(nh == hp) & ~below63(e2);
+                                stale |= same;
+                                cnow = __builtin_amdgcn_inverse_ballot_w64(same) ? P2 - 1 : cnow;
+                                tab.put(hp, P2 - 1);  // (every lane: same bucket, same value)
+                            }
+                        } else {
+                            head(t2);
+                            if (chain2 && !pm1_done) {  // the reference inserts P-1 before it looks P up
+                                if (e2 >= 1) {
+                                    if (lane == e2 - 1)
+                                        tab.put(nh, P2 - 1);
+                                } else if (lane == 0) {
+                                    tab.put((ld32(in + P2 - 1) * kHashMul) >> shift, P2 - 1);
+                                }
+                                asm volatile("" ::: "memory");
+                            }
+                            ncand = tab.get(nh);
+                            head_loads();
+                        }
+                        have_spec = false;
+                        TRACE(2);
+                        {  // the head becomes the current tile: compare -> hit mask, match lengths
+                            const uint32_t ml = matchlen32(na, na2, nc, nc2);
+                            Hraw = ballot64(nc.x == na.x);
+                            tmlw = ml == 32 ? 64u : ml;
+                            a0 = na.x;
+                            th = nh;
+                            tcand = ncand;
+                            t = tn;
+                        }
+                        if (stale)
+                            patch(stale, cnow);
+                        TRACE(3);
+                        uint64_t Vacc = 0, Hpacc = 0;
+                        uint32_t long_lane = 64;
+                        e = e2;
+                        c_in = chain2;
+                        sc_in = sc2;
+                        const uint32_t base = t << 6;
+                        const uint32_t pos = base + lane;
+                        for (;;) {  // ============================================ visits of this tile
+                            const uint64_t Hm = Hraw & ~below63(e);
+                            const uint64_t tl = Hm >> lane;
+                            uint32_t dlo, dhi;
+                            asm("v_ffbl_b32 %0, %1" : "=v"(dlo) : "v"((uint32_t)tl));
+                            asm("v_ffbl_b32 %0, %1" : "=v"(dhi) : "v"((uint32_t)(tl >> 32)));
+                            const uint32_t dist = umin3(dlo, dhi | 32u, 64u);  // 64: no hit from here on
+                            const uint32_t nh_l = lane + dist;
+                            const uint32_t m_nh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nh_l << 2), (int)tmlw);
+                            uint32_t vJ = nh_l + m_nh;
+                            vJ = vJ > lane ? vJ : lane + 1;
+                            vJ = vJ < 64u ? vJ : 64u;
+                            const uint64_t far = ballot64(dist >= run32) & ~below63(e);
+                            const uint32_t lead = ctz64(Hm | (1ull << 63)) - e;
+                            const uint32_t lead_bad = (c_in ^ 1u) & (sc_in + lead > 31 ? 1u : 0u);
+                            if (__builtin_expect((far != 0) | (lead_bad != 0), 0)) {  // (P2, chain2, sc2 are this very state)
+                                hold_fast = true;
+                                quit = 1;
+                                break;
+                            }
+                            uint64_t S = 0;
+                            uint32_t jj = e;
+                            do {
+                                S |= 1ull << jj;
+                                jj = lane_get(vJ, jj);
+                            } while (jj < 64);
+                            uint64_t V, Hp, C;
+                            uint32_t ll, emit2;
+                            auto exit_for = [&](uint32_t lim) {
+                                const uint64_t bl = lanes_below(lim);
+                                const uint64_t Hm_t = Hm & bl, Sx = S & bl;
+                                const uint32_t s_l = 63u - (uint32_t)__builtin_clzll(Sx);  // (lane e is in Sx)
+                                const uint64_t Hx = Hm_t >> s_l;
+                                const uint32_t open = Hx == 0 ? 1u : 0u;  // the literal / scan is still open at lim
+                                Hp = Hm_t & ~(Hm_t - Sx);  // first hit of every segment [start, next start)
+                                const uint64_t bitlim = lim < 64 ? 1ull << lim : 0ull;
+                                V = (((Hp << 1) | (open ? bitlim : 0ull)) - Sx) & bl;
+                                const uint32_t jx = (s_l + ctz64(Hx | (1ull << 63))) & 63u;  // the last hit on the path
+                                const uint32_t mj = lane_get(tmlw, jx);
+                                const uint32_t carried = (Sx == (1ull << e) ? 1u : 0u) & (c_in ^ 1u);
+                                const uint32_t is_long = (open ^ 1u) & (mj == 64 ? 1u : 0u);
+                                const uint32_t pend = base + jx + mj;  // where the last copy ends
+                                chain2 = open ^ 1u;
+                                ll = is_long ? jx : 64u;
+                                P2 = open ? base + lim : (is_long ? base + jx : pend);
+                                sc2 = open ? (carried ? sc_in + lim - e : lim - s_l - 1) : 0u;
+                                emit2 = open ? (carried ? next_emit : base + s_l) : pend;
+                                pm1_done = (open ^ 1u) & (is_long ^ 1u) & (lim == 64 ? 1u : 0u) & (jx + mj == 64 ? 1u : 0u);
+                                const uint64_t Ins = ((Sx & ~(1ull << e)) >> 1) | ((uint64_t)pm1_done << 63);
+                                C = V | Ins;
+                            };
+                            exit_for(64);
+                            {
+                                const bool inC = __builtin_amdgcn_inverse_ballot_w64(C);
+                                uint32_t w = pos & 0xffffu;
+                                if (inC) {
+                                    tab.put(th, pos);
+                                    asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
+                                    w = tab.get(th);
+                                }
+                                uint64_t L = ballot64(inC && w != (pos & 0xffffu));
+                                if (__builtin_expect(L != 0, 0)) {  // two inserted lanes share a bucket: end the visit before the second one
+                                    asm volatile("" ::: "memory");
+                                    if (inC)
+                                        tab.put(th, tcand);  // roll back (lanes of one bucket hold the same old entry)
+                                    uint32_t cut = 64;
+                                    while (L) {
+                                        const uint32_t hv = lane_get(th, ctz64(L));
+                                        const uint64_t G = ballot64(inC && th == hv);
+                                        L &= ~G;
+                                        const uint64_t G2 = G & (G - 1);
+                                        const uint32_t second = ctz64(G2);
+                                        cut = second < cut ? second : cut;
+                                    }
+                                    const bool bad_cut = cut <= e || cut >= 64;
+                                    poisoned = poisoned || bad_cut;
+                                    exit_for(bad_cut ? e + 1 : cut);
+                                    if (__builtin_amdgcn_inverse_ballot_w64(C))
+                                        tab.put(th, pos);  // lanes below a cut share no bucket
+                                    UNIFORM_JOIN();
+                                }
+                            }
+                            next_emit = emit2;
+                            Vacc |= V;
+                            Hpacc |= Hp;
+                            long_lane = ll;  // (64: none)
+                            if (__builtin_expect(poisoned | (ll < 64) | ((P2 >> 6) != t), 1))
+                                break;
+                            // the same tile again (after a cut): insert P-1, then give the lanes whose bucket
+                            // was written since their lookup the new candidate
+                            const uint32_t e2s = P2 & 63u;
+                            if (chain2 && lane == e2s - 1)
+                                tab.put(th, pos);
+                            asm volatile("" ::: "memory");
+                            const uint32_t cn = tab.get(th);
+                            const uint64_t st = ballot64(cn != tcand) & ~below63(e2s);
+                            if (st)
+                                patch(st, cn);
+                            e = e2s;
+                            c_in = chain2;
+                            sc_in = sc2;
+                        }
+                        TRACE(4);
+                        // ---- a match that runs past its 32 local bytes: its end is the next state
+                        uint32_t Lip = 0, Lcnd = 0, Lm = 0;
+                        const bool has_long = long_lane < 64;
+                        if (__builtin_expect(has_long, 0)) {
+                            Lip = base + long_lane;
+                            Lcnd = lane_get(tcand, long_lane);
+                            Lm = match_length<kMatchPieces>(in, Lcnd, Lip, n, lane, 32);
+                            P2 = Lip + Lm;
+                            next_emit = P2;
+                            chain2 = 1;
+                            sc2 = 0;
+                            pm1_done = 0;
+                        }
+                        TRACE(5);
+                        // ---- the token goes on (or stays: the block's tail, a state for the general code, poison)
+                        const bool cont = !((quit != 0) | poisoned | (P2 + kFastMargin > ip_limit));
+                        if (cont)
+                            team_publish(team.ptok, team_pack_parse(myturn + 1, P2, chain2, sc2, pm1_done, next_emit));
+                        if (SZ_TEAM_PRIO)
+                            __builtin_amdgcn_s_setprio(0);
+                        TRACE(6);
+                        // ---- element writer of this tile: where do its elements begin?
+                        if (!own_op) {
+                            bool lost;
+                            const uint64_t ot = team_wait(team.otok, myturn, lost);
+                            op = (uint32_t)ot & 0x1ffffu;
+                            poisoned = poisoned || lost || (((uint32_t)ot >> 17) & 1u);
+                            own_op = true;
+                        }
+                        TRACE(7);
+                        if (__builtin_expect(Hpacc != 0, 1)) {
+                            const uint32_t jfirst = ctz64(Hpacc);
+                            const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hpacc);
+                            uint64_t Lit = Vacc & ~Hpacc & below63(jlast);
+                            if (acc_open) {
+                                // a literal was open on entry: it ends at the first hit (one tag byte, at most 33
+                                // bytes by construction); its bytes of the tiles before come from memory
+                                const uint32_t len = base + jfirst - acc_emit;
+                                const uint32_t nprev = base - acc_emit;
+                                const uint32_t cur = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane - nprev) << 2), (int)a0);
+                                uint32_t lbyte = cur;
+                                if (lane < nprev && lane < len)
+                                    lbyte = in[acc_emit + lane];
+                                if (lane == 0)
+                                    out[op] = (uint8_t)((len - 1) << 2);
+                                if (lane < len)
+                                    out[op + 1 + lane] = (uint8_t)lbyte;
+                                UNIFORM_JOIN();
+                                poisoned = poisoned || len > 60;
+                                op += 1 + len;
+                                Lit &= ~below63(jfirst);
+                            }
+                            const uint64_t RS = Lit & ~(Lit << 1);
+                            const uint64_t HC = has_long ? Hpacc & ~(1ull << long_lane) : Hpacc;
+                            const bool is_lit = __builtin_amdgcn_inverse_ballot_w64(Lit);
+                            const bool run_start = __builtin_amdgcn_inverse_ballot_w64(RS);
+                            const bool is_hit = __builtin_amdgcn_inverse_ballot_w64(HC);
+                            const uint32_t runlen = (uint32_t)__builtin_ctzll((Hpacc >> lane) | (1ull << 63));
+                            const uint32_t abyte = a0 & 0xffu;
+                            const uint32_t off = pos - tcand;
+                            const bool short_form = tmlw < 12 && off < 2048;
+                            uint32_t cnt = 0, word = 0;
+                            if (is_lit) {
+                                cnt = run_start ? 2 : 1;
+                                word = run_start ? (((runlen - 1) << 2) | (abyte << 8)) : abyte;
+                            } else if (is_hit) {
+                                cnt = short_form ? 2 : 3;
+                                word = short_form ? (1u | ((tmlw - 4) << 2) | ((off >> 8) << 5) | ((off & 0xffu) << 8))
+                                                  : (2u | ((tmlw - 1) << 2) | (off << 8));
+                            }
+                            const uint32_t incl = wave_inclusive_sum(cnt);
+                            uint8_t *o = out + (op + (incl - cnt));
+                            if (cnt >= 1) o[0] = (uint8_t)word;
+                            if (cnt >= 2) o[1] = (uint8_t)(word >> 8);
+                            if (cnt >= 3) o[2] = (uint8_t)(word >> 16);
+                            UNIFORM_JOIN();
+                            op += lane_get(incl, 63);
+                        }
+                        if (__builtin_expect(has_long, 0))
+                            op = emit_copy(out, op, Lip - Lcnd, Lm, lane);
+                        TRACE(8);
+                        if (!cont) {  // this wave goes on alone (general code below, or the end of the block)
+                            P = P2;
+                            chain = chain2 != 0;
+                            sc = sc2;
+                            break;
+                        }
+                        team_publish(team.otok, (uint64_t)(op | (poisoned ? 1u << 17 : 0u)) | ((uint64_t)(myturn + 1) << 42));
+                        own_op = false;
+                        holder = false;
+                        myturn += kTeamW;
+                        // ---- head of this wave's next tile, ahead of its token: the next wave takes the tile of P2
+                        const uint32_t tnext = (P2 >> 6) + (kTeamW - 1);
+                        if ((tnext << 6) + kFastMargin <= ip_limit) {
+                            head(tnext);
+                            ncand = tab.get(nh);
+                            head_loads();
+                            have_spec = true;
+                        }
+                        TRACE(9);
+                    }
+                    if (team_gone)
+                        break;
+                    if (!chain)
+                        scan_base = P - sc;
+                    want_prep(P - (chain ? 1u : 0u), chain);
+                    continue;
+                }
+            }
 #ifndef SZ_NO_FAST
-            if (kFast && chain && !hold_fast && P + kFastMargin <= ip_limit) {
+            if (kFast && kTeamW == 1 && chain && !hold_fast && P + kFastMargin <= ip_limit) {
                 // =================================================== FAST DENSE PATH (fixed tiles)
                 // Compressible data spends its time here.  The block is cut into fixed tiles of 64
                 // positions (lane l of tile t = position 64 t + l), so the bytes of a tile come out of
@@ -1391,6 +1853,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             PROF_LAP(7);
         }
         PROF_FLUSH();
+        if constexpr (kTeamW > 1) {
+            if (team_gone)  // another wave finishes (or finished) the block; a lost wave says so
+                return team_lost ? 0xfffffffeu : kTeamNotMine;
+        }
         if (next_emit < n) {  // remainder literal
             emit_lit(next_emit, n - next_emit);
             next_emit = n;
@@ -1417,6 +1883,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
     }
     if (next_emit < n)  // blocks shorter than the 15-byte margin are one literal
         op = emit_literal<(kLean ? 0 : 16)>(out, op, in + next_emit, n - next_emit, lane);
+    if constexpr (kTeamW > 1) {
+        if (n >= 1024)  // the waves that wait for a token leave
+            team_publish(team.ptok, (uint64_t)kTeamDoneTurn << 42);
+    }
     return poisoned ? 0xfffffffeu : op;
 }
 
@@ -1634,6 +2104,69 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
     }
 }
 
+// Team kernel (round 3): workgroups of kTeamWaves wavefronts that compress ONE block together, sharing one
+// hash table in LDS (see "wave teams" above); four workgroups per CU, persistent grid over one device-wide
+// block counter.  No table in global memory: every lookup stays inside the CU.
+#ifndef SZ_TEAM_WAVES
+#define SZ_TEAM_WAVES 0  // 0: the multi-wave kernel above takes compressible launches; 2..4: this kernel does
+#endif
+static constexpr int kTeamWaves = SZ_TEAM_WAVES > 1 ? SZ_TEAM_WAVES : 2;
+__global__ __launch_bounds__(64 * kTeamWaves) __attribute__((amdgpu_waves_per_eu(kTeamWaves, kTeamWaves))) void compress_blocks_team_kernel(
+    const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
+    uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
+    uint32_t *__restrict__ out_len, uint32_t flags, uint32_t *__restrict__ select,
+    const uint32_t *__restrict__ queue, uint32_t auto_mode)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
+    __shared__ __attribute__((aligned(16))) uint64_t tokens[2];
+    __shared__ uint32_t next_block;
+    if (auto_mode && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
+        return;
+    const uint32_t n_work = queue ? uni(select[3]) : n_blocks;
+    if (blockIdx.x >= n_work)
+        return;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const HashTab<true> tab{lds_tab, nullptr, nullptr};
+    WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr};
+    for (;;) {
+        if (wave == 0) {  // one queue for the whole grid (address through VGPRs: see the multi-wave kernel)
+            uint32_t b0 = 0;
+            if (lane == 0) {
+                uint64_t qa = (uint64_t)(uintptr_t)(select + 2);
+                uint32_t qlo = (uint32_t)qa, qhi = (uint32_t)(qa >> 32);
+                asm volatile("" : "+v"(qlo), "+v"(qhi));
+                b0 = atomicAdd(reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)qhi << 32) | qlo)), 1u);
+            }
+            b0 = uni(b0);
+            __hip_atomic_store(&next_block, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();  // every wave of the team is past the block before (it left on the "done" token)
+        uint32_t b = uni(__hip_atomic_load(&next_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (wave == 0) {  // only now: a wave still polling for "done" must not find an empty token instead
+            __hip_atomic_store(&tokens[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&tokens[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();  // (everyone has the index and sees fresh tokens before any wave goes on)
+        if (b >= n_work)
+            break;
+        if (queue)
+            b = uni(queue[b]);
+        const uint32_t n = block_length(in_len, total_len, in_stride, b);
+        if (n > kMaxBlock) {
+            out_len[b] = 0xffffffffu;
+            continue;
+        }
+#ifdef SZ_TRACE
+        team.trace = b < kTraceBlocks && g_trace ? g_trace + ((size_t)b * kTeamWaves + wave) * kTraceCap : nullptr;
+#endif
+        const uint32_t op = compress_one_block<0, true, HashTab<true>, false, true, SZ_MATCH_PIECES, WaveTeam<kTeamWaves>>(
+            tab, src + (uint64_t)b * in_stride, n, dst + (uint64_t)b * dst_stride, flags, lane, team);
+        if (op != kTeamNotMine)
+            out_len[b] = op;  // (a9) the wave that finished the block; every lane, same address, same value
+    }
+}
+
 static constexpr uint32_t kSmallBlockMax = 8192;
 
 // Small fixed-size blocks (<= 8 KiB each, e.g. 4 KiB pages): the table is 2 * T bytes of dynamic LDS
@@ -1696,6 +2229,15 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
                            dual->queue, dual->select);
     if (dual_ok) {
         // enough blocks to keep kGroupWaves waves per SIMD busy on every CU: persistent grid
+#if SZ_TEAM_WAVES > 1
+        {
+            const uint32_t tgrid = n_blocks < dual->n_slots ? n_blocks : dual->n_slots;
+            hipLaunchKernelGGL(compress_blocks_team_kernel, dim3(tgrid), dim3(64 * kTeamWaves), 0, stream, src, in_stride,
+                               d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->select,
+                               route ? dual->queue : (const uint32_t *)nullptr, sampled ? 1u : 0u);
+            return hipGetLastError();
+        }
+#endif
         uint32_t grid = (n_blocks + kGroupWaves - 1) / kGroupWaves;
         grid = grid < dual->n_slots ? grid : dual->n_slots;
         hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(64 * kGroupWaves), 0, stream, src, in_stride,
