@@ -30,7 +30,7 @@ namespace {
 // that two host threads launching on the same stream (e.g. both on the NULL stream) cannot
 // interleave those sequences -- on the stream the kernels of one call then run back to back.
 struct DualSlot {
-    szk::DualScratch sc{nullptr, nullptr, nullptr, 0, 0, 0, szk::kDualAuto};
+    szk::DualScratch sc{nullptr, nullptr, nullptr, 0, 0, 0, szk::kDualAuto, szk::kKernelTeam};
     std::mutex launch_mu;
 };
 std::mutex g_dual_mutex;
@@ -38,12 +38,14 @@ std::map<std::pair<int, hipStream_t>, std::unique_ptr<DualSlot>> g_dual;
 
 int kernel_mode()
 {
-    // SZ_KERNEL=single: never the multi-wave kernel; SZ_KERNEL=dual: always, from two blocks up (tests);
-    // default (auto): when there are enough blocks to give every SIMD two waves, a sample of the data
-    // decides; SZ_KERNEL=route: per block inside the launch (the single kernel hands compressible blocks
-    // over).  Read on every call so that a test can switch modes inside one process.
+    // default (auto): when there are enough blocks to give every SIMD two waves, a sample of the data decides
+    // between the single kernel (incompressible) and the team kernel (compressible).  SZ_KERNEL=single: always
+    // the single kernel; team: always the team kernel, from two blocks up; dual: always the multi-wave kernel
+    // (round 1-2's kernel for compressible data, kept for comparison), from two blocks up; route: per block
+    // inside the launch (the single kernel hands compressible blocks to the multi-wave kernel).  Read on every
+    // call so that a test can switch modes inside one process.
     const char *e = getenv("SZ_KERNEL");
-    return !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : strcmp(e, "route") == 0 ? 3 : 0;
+    return !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : strcmp(e, "route") == 0 ? 3 : strcmp(e, "team") == 0 ? 4 : 0;
 }
 
 // The workspace slot of (current device, stream) for a launch of n_blocks, or nullptr when the
@@ -64,7 +66,7 @@ DualSlot *dual_slot_for(hipStream_t stream, uint32_t n_blocks, szk::DualScratch 
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             return nullptr;
         const uint32_t n_slots = 4u * (uint32_t)cus;  // four workgroups per CU, kGroupWaves waves each
-        const uint32_t min_blocks = mode == 2 ? 2u : 2u * n_slots;
+        const uint32_t min_blocks = (mode == 2 || mode == 4) ? 2u : 2u * n_slots;
         if (n_blocks < min_blocks)
             return nullptr;  // (a 130-byte sz_compress never pays for the 64 MiB workspace)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -96,8 +98,11 @@ DualSlot *dual_slot_for(hipStream_t stream, uint32_t n_blocks, szk::DualScratch 
     }
     DualSlot *s = it->second.get();
     *view = s->sc;
-    view->mode = mode == 2 ? szk::kDualAlways : mode == 3 ? szk::kDualRoute : szk::kDualAuto;
-    view->min_blocks = mode == 2 ? 2u : 2u * s->sc.n_slots;
+    view->mode = (mode == 2 || mode == 4) ? szk::kDualAlways : mode == 3 ? szk::kDualRoute : szk::kDualAuto;
+    // compressible launches: the team kernel (a two-wave team on the LDS table + two global-table waves per
+    // workgroup), unless the multi-wave kernel is asked for by name (SZ_KERNEL=dual; route hands its blocks to it too)
+    view->kernel = (mode == 2 || mode == 3) ? szk::kKernelMulti : szk::kKernelTeam;
+    view->min_blocks = (mode == 2 || mode == 4) ? 2u : 2u * s->sc.n_slots;
     if (n_blocks < view->min_blocks)
         return nullptr;
     return s;

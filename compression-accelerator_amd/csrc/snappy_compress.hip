@@ -436,6 +436,8 @@ struct WaveTeam {
     uint64_t *otok;  // LDS: output-position token
     uint32_t wave;   // this wave's place in the team (0 starts every block)
     unsigned long long *trace;  // (-DSZ_TRACE builds: this wave's stamps for this block, or null)
+    uint8_t *scr;    // LDS: 256 bytes of scratch of this wave's own (lanes that share a bucket inside a tile)
+    uint32_t *bar;   // LDS: arrivals at the team's barrier (the workgroup may hold waves that are not of the team)
 };
 static constexpr uint32_t kTeamDoneTurn = 0x3fffffu;  // turn field of a token: the block is finished
 static constexpr uint32_t kTeamNotMine = 0xfffffffcu; // return value of the waves that did not finish the block
@@ -462,6 +464,28 @@ __device__ __forceinline__ void team_publish(uint64_t *slot, uint64_t v)
     asm volatile("s_wakeup" ::: "memory");
 #endif
 }
+// Barrier among the kWaves waves of a team (s_barrier would wait for every wave of the workgroup, and the hybrid
+// kernel's workgroups hold waves that compress other blocks): a counter of arrivals that only grows; a wave waits
+// until the count has passed the multiple of kWaves its own arrival belongs to.  LDS accesses of a wave made
+// before its arrival are complete before it (the wait), those of the others are visible after it.
+template <int W>
+__device__ __forceinline__ void team_barrier(uint32_t *bar, uint32_t lane)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t mine = 0;
+    if (lane == 0)
+        mine = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    mine = uni(mine);
+    const uint32_t target = (mine / W + 1u) * W;
+    for (uint32_t spin = 0; spin < SZ_TEAM_SPIN_CAP; spin++) {
+        const uint32_t now = uni(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int32_t)(now - target) >= 0)
+            break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
 // waits until the token in `slot` carries `turn` (or "done"); returns the token, or 0 with *lost = true
 __device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t turn, bool &lost)
 {
@@ -645,7 +669,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 const uint32_t nvec = (1u << log2T) >> 3;
                 for (uint32_t i = team.wave * 64u + lane; i < nvec; i += 64u * kTeamW)
                     reinterpret_cast<u32x4 *>(tab.lds)[i] = u32x4{0, 0, 0, 0};
-                __syncthreads();
+                team_barrier<kTeamW>(team.bar, lane);
             } else {
                 tab.clear(log2T, lane);
             }
@@ -741,57 +765,144 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     // not take is kept by the wave that meets it: it runs the general code below (it owns the
                     // output position then) and comes back here, or ends the block.
                     first_scan = false;
-                    uint32_t t = 0, e = 0, sc_in = 0, c_in = 1;
-                    uint32_t a0 = 0, th = 0, tcand = 0, tmlw = 0;
-                    uint64_t Hraw = 0;
-                    u32x4 na = {0, 0, 0, 0}, na2 = {0, 0, 0, 0}, nc = {0, 0, 0, 0}, nc2 = {0, 0, 0, 0};
-                    uint32_t nh = 0, ncand = 0, tn = 0;
-                    bool have_spec = false;
+                    uint32_t t = 0xffffffffu, e = 0, sc_in = 0, c_in = 1;
+                    uint32_t a0 = 0, th = 0, tcand = 0, tmlw = 0, X = 0, Y = 0, Z = 0;
+                    uint32_t Glo = 0, Ghi = 0;  // lanes of a shared bucket: the EARLIER lanes of this tile with this lane's hash
+                    uint64_t Hraw = 0, farmask = 0;
+                    u32x4 na = {0, 0, 0, 0}, na2 = {0, 0, 0, 0};
+                    // The head of a tile (its bytes, hashes, table lookups, candidate strings, compares, jumps, shared
+                    // buckets) is made in ONE place, at the top of the turn loop: ahead of the token for the tile this
+                    // wave expects next, or -- the parse went elsewhere, or this wave comes from the general code -- with
+                    // the token in hand for the tile of P2.
+                    bool have_head = false, need_head = holder;
+                    uint32_t thead = P >> 6;
                     uint32_t P2 = P, sc2 = 0, chain2 = 1, pm1_done = 0, quit = 0;
-                    auto head = [&](uint32_t tt) {  // bytes and hashes of tile tt
-                        const uint32_t k = tt >> 1;  // buffer k = bytes [128 k, 128 k + 256) holds the tile + 32
-                        if (k != kcur)
-                            advance_bufs(k);
-                        const uint32_t i0 = ((tt & 1u) << 6) + lane4;
-                        uint32_t d[9];
-#pragma unroll
-                        for (int q = 0; q < 9; q++)
-                            d[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i0 + 4 * q), (int)wcur);
-                        na.x = __builtin_amdgcn_alignbyte(d[1], d[0], lane3);
-                        na.y = __builtin_amdgcn_alignbyte(d[2], d[1], lane3);
-                        na.z = __builtin_amdgcn_alignbyte(d[3], d[2], lane3);
-                        na.w = __builtin_amdgcn_alignbyte(d[4], d[3], lane3);
-                        na2.x = __builtin_amdgcn_alignbyte(d[5], d[4], lane3);
-                        na2.y = __builtin_amdgcn_alignbyte(d[6], d[5], lane3);
-                        na2.z = __builtin_amdgcn_alignbyte(d[7], d[6], lane3);
-                        na2.w = __builtin_amdgcn_alignbyte(d[8], d[7], lane3);
-                        nh = (na.x * kHashMul) >> shift;
-                        tn = tt;
+                    const uint32_t lb_lo = lane < 32 ? (1u << lane) - 1u : 0xffffffffu;  // bits of the lanes below this one
+                    const uint32_t lb_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+                    // Bytes of the block near the tile in registers (one dword per lane, one coalesced load): buffer of
+                    // tile tt = bytes [64 tt - 128, 64 tt + 128) -- the tile + 32 for its own strings, and the two tiles
+                    // before it, where the candidates are that a lookup made ahead of the token can have missed.
+                    uint32_t tbuf = 0, tb_base = 0, tb_tile = 0xffffffffu;
+                    uint32_t tnbuf = 0, tn_sh = 0, tn_tile = 0xffffffffu;  // prefetched (as loaded; shift applied when it becomes current)
+                    auto tb_fetch = [&](uint32_t tt, uint32_t &sh8) -> uint32_t {
+                        const uint32_t o = (tt >= 2 ? (tt << 6) - 128u : 0u) + 4u * lane;
+                        const uint32_t oc = o < n - 4u ? o : n - 4u;  // stay inside the block ...
+                        const uint32_t sh = o - oc < 3u ? o - oc : 3u;
+                        sh8 = 8u * sh;                                 // ... and keep its last bytes where they belong
+                        return ld32(in + oc);
                     };
-                    auto head_loads = [&]() {
-                        nc = ld128(in + ncand);  // ncand < pos, pos + 32 <= n here
-                        nc2 = ld128(in + ncand + 16);
-                    };
-                    // candidates changed for the lanes in `sel` (their bucket was written after their lookup):
-                    // the candidate's string again, hit bit and match length merged in
-                    auto patch = [&](uint64_t sel, uint32_t cnow) {
-                        const bool on = __builtin_amdgcn_inverse_ballot_w64(sel);
-                        bool hit = false;
-                        if (on) {
-                            tcand = cnow;
-                            const u32x4 c = ld128(in + cnow), c2 = ld128(in + cnow + 16);
-                            const uint32_t ml = matchlen32(na, na2, c, c2);
-                            tmlw = ml == 32 ? 64u : ml;
-                            hit = c.x == na.x;
-                        }
-                        UNIFORM_JOIN();
-                        Hraw = (Hraw & ~sel) | ballot64(on && hit);
+                    // Where the parse goes from each lane, with what the exit of a visit needs to know about the last
+                    // jump beside it, so that the walk's last v_readlane IS the exit state:
+                    //   X: bits 0..5 target lane (next hit at or after this lane, then past its match), bit 6 the jump
+                    //      leaves the tile (bits 0..5 then name the lane itself), bit 7 no hit from here on (the scan stays open), bit 8 that hit's match reaches 32
+                    //      bytes (long), bits 10..15 lane of that hit, bits 16..23 where the parse stands afterwards
+                    //      relative to the tile;
+                    //   Y: the state a visit that ends with this lane's jump hands on, as it travels in the token
+                    //      (position, chain flag, "copy ends with the tile", scan index); Z: the pending literal's start.
+                    auto jumps = [&]() {
+                        const uint64_t tl = Hraw >> lane;
+                        uint32_t dlo, dhi;
+                        asm("v_ffbl_b32 %0, %1" : "=v"(dlo) : "v"((uint32_t)tl));
+                        asm("v_ffbl_b32 %0, %1" : "=v"(dhi) : "v"((uint32_t)(tl >> 32)));
+                        const uint32_t dist = umin3(dlo, dhi | 32u, 64u);  // 64: no hit from here on
+                        const uint32_t nh_l = lane + dist;
+                        const uint32_t m_nh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nh_l << 2), (int)tmlw);
+                        const bool open = dist >= 64u;
+                        const bool lng = !open && m_nh == 64u;
+                        const uint32_t sum = nh_l + m_nh;
+                        uint32_t tgt = sum > lane ? sum : lane + 1;  // (always so for a hit: ml >= 4; keeps the walk finite whatever memory holds)
+                        tgt = (open || tgt > 64u) ? 64u : tgt;
+                        const uint32_t p2off = open ? 64u : (lng ? nh_l : sum);
+                        const uint32_t base_ = t << 6;
+                        // (a lane whose jump leaves the tile points at itself, bit 6 set: the walk below may then take
+                        // steps past its end -- they change nothing -- and needs no branch per element)
+                        X = (tgt >= 64u ? lane | 64u : tgt) | (open ? 1u << 7 : 0u) | (lng ? 1u << 8 : 0u) | ((nh_l & 63u) << 10) |
+                            ((p2off & 0xffu) << 16);
+                        Y = (base_ + p2off) | (open ? 0u : 1u << 17) | ((!open && !lng && sum == 64u) ? 1u << 18 : 0u) |
+                            (open ? (63u - lane) << 19 : 0u);
+                        Z = open ? base_ + lane : base_ + p2off;
+                        // lanes from which a scan could reach probe 32 inside the tile (32 hit-free lanes in a row)
+                        farmask = ballot64(dist >= run32);
                     };
                     for (;;) {  // ================================================ one turn per trip
                         P2 = uni(P2); sc2 = uni(sc2); chain2 = uni(chain2); pm1_done = uni(pm1_done); quit = uni(quit);
                         holder = unib(holder); own_op = unib(own_op); myturn = uni(myturn); next_emit = uni(next_emit);
-                        op = uni(op); poisoned = unib(poisoned); have_spec = unib(have_spec); tn = uni(tn); kcur = uni(kcur);
-                        TRACE(0);
+                        op = uni(op); poisoned = unib(poisoned); have_head = unib(have_head); need_head = unib(need_head);
+                        t = uni(t); thead = uni(thead); tb_base = uni(tb_base); tb_tile = uni(tb_tile); tn_tile = uni(tn_tile);
+                        TRACE(0); MARK("T0");
+                        if (need_head) {
+                            // ---- HEAD of tile thead
+                            const uint32_t tt = thead;
+                            if (tt != tb_tile) {
+                                if (tt == tn_tile) {
+                                    tbuf = tnbuf >> tn_sh;
+                                } else {
+                                    uint32_t sh8;
+                                    const uint32_t v = tb_fetch(tt, sh8);
+                                    tbuf = v >> sh8;
+                                }
+                                tb_tile = tt;
+                                tb_base = tt >= 2 ? (tt << 6) - 128u : 0u;
+                            }
+                            {
+                                const uint32_t i0 = ((tt << 6) - tb_base) + lane4;
+                                uint32_t d[9];
+#pragma unroll
+                                for (int q = 0; q < 9; q++)
+                                    d[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i0 + 4 * q), (int)tbuf);
+                                na.x = __builtin_amdgcn_alignbyte(d[1], d[0], lane3);
+                                na.y = __builtin_amdgcn_alignbyte(d[2], d[1], lane3);
+                                na.z = __builtin_amdgcn_alignbyte(d[3], d[2], lane3);
+                                na.w = __builtin_amdgcn_alignbyte(d[4], d[3], lane3);
+                                na2.x = __builtin_amdgcn_alignbyte(d[5], d[4], lane3);
+                                na2.y = __builtin_amdgcn_alignbyte(d[6], d[5], lane3);
+                                na2.z = __builtin_amdgcn_alignbyte(d[7], d[6], lane3);
+                                na2.w = __builtin_amdgcn_alignbyte(d[8], d[7], lane3);
+                            }
+                            th = (na.x * kHashMul) >> shift;
+                            a0 = na.x;
+                            t = tt;
+                            tcand = tab.get(th);  // (ahead of the token: checked against the table when it comes)
+                            const u32x4 nc = ld128(in + tcand);  // tcand < pos, pos + 32 <= n here
+                            const u32x4 nc2 = ld128(in + tcand + 16);
+                            if (((tt + kTeamW) << 6) < n) {  // this wave's likely tile after this one: its bytes are on their way
+                                tnbuf = tb_fetch(tt + kTeamW, tn_sh);
+                                tn_tile = tt + kTeamW;
+                            }
+                            {
+                                // Lanes of this tile that share a bucket: G(lane) = the earlier lanes with this lane's hash.
+                                // Two INSERTED lanes of one bucket end a visit before the second one (the later lane should
+                                // have seen the earlier one); which lanes are inserted is only known on the token, but with
+                                // these masks the test is two ANDs and a ballot there: no read-back of the table, nothing to
+                                // roll back.  (256 bytes of scratch in LDS find the candidates: every lane writes its number
+                                // under its hash's low byte and reads the entry back; a lane that reads another number shares
+                                // its entry -- a shared bucket or just a shared low byte, told apart by the full hashes.)
+                                Glo = 0;
+                                Ghi = 0;
+                                uint8_t *slot = team.scr + (th & 255u);
+                                __hip_atomic_store(slot, (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                asm volatile("" ::: "memory");
+                                const uint32_t r = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                uint64_t losers = ballot64(r != lane);
+                                while (losers) {
+                                    const uint32_t hv = lane_get(th, ctz64(losers));
+                                    const bool mine = th == hv;
+                                    const uint64_t G = ballot64(mine);
+                                    losers &= ~G;
+                                    Glo = mine ? (uint32_t)G & lb_lo : Glo;
+                                    Ghi = mine ? (uint32_t)(G >> 32) & lb_hi : Ghi;
+                                }
+                            }
+                            {  // candidates' strings against the lanes' own: hit mask, match lengths for the walk (4..31, or 64: goes on)
+                                const uint32_t ml = matchlen32(na, na2, nc, nc2);
+                                Hraw = ballot64(nc.x == na.x);
+                                tmlw = ml == 32 ? 64u : ml;
+                            }
+                            jumps();
+                            have_head = true;
+                            need_head = false;
+                        }
+                        TRACE(10); MARK("T10");
                         if (!holder) {
                             bool lost;
                             const uint64_t tok = team_wait(team.ptok, myturn, lost);
@@ -807,146 +918,156 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             next_emit = (uint32_t)(tok >> 25) & 0x1ffffu;
                             holder = true;
                         }
-                        TRACE(1);
+                        TRACE(1); MARK("T1");
                         if (SZ_TEAM_PRIO)
                             __builtin_amdgcn_s_setprio(SZ_TEAM_PRIO);
                         // ---- enter the tile of P2
                         const uint32_t t2 = P2 >> 6, e2 = P2 & 63u;
+                        if (__builtin_expect(!(have_head && t2 == t), 0)) {  // not the tile this wave has a head of: make it now
+                            thead = t2;
+                            need_head = true;
+                            have_head = false;
+                            continue;
+                        }
+                        have_head = false;
                         const uint32_t acc_emit = next_emit;   // start of the literal that is open on entry (if any)
                         const bool acc_open = chain2 == 0;
-                        uint64_t stale = 0;
-                        uint32_t cnow = 0;
-                        if (have_spec && t2 == tn) {
-                            // the head issued ahead is this tile: check its lookups against the table
-                            cnow = tab.get(nh);
-                            stale = ballot64(cnow != ncand);
-                            if (chain2 && !pm1_done) {  // P-1 goes in first: the lanes of its bucket then see it
-                                uint32_t hp;
-                                if (e2 >= 1)
-                                    hp = lane_get(nh, e2 - 1);
-                                else
-                                    hp = uni((ld32(in + P2 - 1) * kHashMul) >> shift);
-                                const uint64_t same = ballot64(nh == hp) & ~below63(e2);
-                                stale |= same;
-                                cnow = __builtin_amdgcn_inverse_ballot_w64(same) ? P2 - 1 : cnow;
-                                tab.put(hp, P2 - 1);  // (every lane: same bucket, same value)
+                        const uint32_t base = t << 6;
+                        const uint32_t pos = base + lane;
+                        // The reference inserts P-1 before it looks P up; then the head's lookups are checked against the
+                        // table as it stands now (the lanes the parse can still reach): a lane whose bucket was written
+                        // since -- by the tiles in between, or by P-1 just now -- gets the new candidate.
+                        if (chain2 && !pm1_done) {
+                            if (e2 >= 1) {
+                                if (lane == e2 - 1)
+                                    tab.put(th, P2 - 1);
+                            } else if (lane == 0) {
+                                tab.put((ld32(in + P2 - 1) * kHashMul) >> shift, P2 - 1);
                             }
-                        } else {
-                            head(t2);
-                            if (chain2 && !pm1_done) {  // the reference inserts P-1 before it looks P up
-                                if (e2 >= 1) {
-                                    if (lane == e2 - 1)
-                                        tab.put(nh, P2 - 1);
-                                } else if (lane == 0) {
-                                    tab.put((ld32(in + P2 - 1) * kHashMul) >> shift, P2 - 1);
-                                }
-                                asm volatile("" ::: "memory");
-                            }
-                            ncand = tab.get(nh);
-                            head_loads();
+                            asm volatile("" ::: "memory");
                         }
-                        have_spec = false;
-                        TRACE(2);
-                        {  // the head becomes the current tile: compare -> hit mask, match lengths
-                            const uint32_t ml = matchlen32(na, na2, nc, nc2);
-                            Hraw = ballot64(nc.x == na.x);
-                            tmlw = ml == 32 ? 64u : ml;
-                            a0 = na.x;
-                            th = nh;
-                            tcand = ncand;
-                            t = tn;
-                        }
-                        if (stale)
-                            patch(stale, cnow);
-                        TRACE(3);
+                        uint32_t newc = tab.get(th);
+                        uint64_t sel = ballot64(newc != tcand) & ~below63(e2);
+                        TRACE(2); MARK("T2");
                         uint64_t Vacc = 0, Hpacc = 0;
+                        uint64_t Cacc = 0;  // lanes of this tile whose table entry this turn has written
                         uint32_t long_lane = 64;
                         e = e2;
                         c_in = chain2;
                         sc_in = sc2;
-                        const uint32_t base = t << 6;
-                        const uint32_t pos = base + lane;
                         for (;;) {  // ============================================ visits of this tile
-                            const uint64_t Hm = Hraw & ~below63(e);
-                            const uint64_t tl = Hm >> lane;
-                            uint32_t dlo, dhi;
-                            asm("v_ffbl_b32 %0, %1" : "=v"(dlo) : "v"((uint32_t)tl));
-                            asm("v_ffbl_b32 %0, %1" : "=v"(dhi) : "v"((uint32_t)(tl >> 32)));
-                            const uint32_t dist = umin3(dlo, dhi | 32u, 64u);  // 64: no hit from here on
-                            const uint32_t nh_l = lane + dist;
-                            const uint32_t m_nh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nh_l << 2), (int)tmlw);
-                            uint32_t vJ = nh_l + m_nh;
-                            vJ = vJ > lane ? vJ : lane + 1;
-                            vJ = vJ < 64u ? vJ : 64u;
-                            const uint64_t far = ballot64(dist >= run32) & ~below63(e);
-                            const uint32_t lead = ctz64(Hm | (1ull << 63)) - e;
-                            const uint32_t lead_bad = (c_in ^ 1u) & (sc_in + lead > 31 ? 1u : 0u);
-                            if (__builtin_expect((far != 0) | (lead_bad != 0), 0)) {  // (P2, chain2, sc2 are this very state)
-                                hold_fast = true;
-                                quit = 1;
-                                break;
+                            if (sel) {
+                                // ---- PATCH: new candidates for the lanes in `sel`: their strings (out of the register buffer:
+                                // no memory access on the token's path, unless a candidate lies before it), hit bit and match
+                                // length merged in, jumps redone
+                                const bool on = __builtin_amdgcn_inverse_ballot_w64(sel);
+                                u32x4 c, c2;
+                                if (__builtin_expect(ballot64(on && newc < tb_base) == 0, 1)) {
+                                    const uint32_t r = on ? newc - tb_base : 0u;  // (every lane takes part in the shuffles)
+                                    const uint32_t i0 = (r >> 2) << 2, sh = r & 3u;
+                                    uint32_t d[9];
+#pragma unroll
+                                    for (int q = 0; q < 9; q++)
+                                        d[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i0 + 4 * q), (int)tbuf);
+                                    c.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+                                    c.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+                                    c.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+                                    c.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
+                                    c2.x = __builtin_amdgcn_alignbyte(d[5], d[4], sh);
+                                    c2.y = __builtin_amdgcn_alignbyte(d[6], d[5], sh);
+                                    c2.z = __builtin_amdgcn_alignbyte(d[7], d[6], sh);
+                                    c2.w = __builtin_amdgcn_alignbyte(d[8], d[7], sh);
+                                } else {
+                                    const uint32_t cc = on ? newc : 0u;
+                                    c = ld128(in + cc);
+                                    c2 = ld128(in + cc + 16);
+                                }
+                                const uint32_t ml = matchlen32(na, na2, c, c2);
+                                tcand = on ? newc : tcand;
+                                tmlw = on ? (ml == 32 ? 64u : ml) : tmlw;
+                                Hraw = (Hraw & ~sel) | ballot64(on && c.x == na.x);
+                                jumps();
                             }
-                            uint64_t S = 0;
-                            uint32_t jj = e;
+                            TRACE(3); MARK("T3");
+                            const uint64_t keep = ~below63(e);  // the lanes the parse can still reach
+                            const uint64_t Hm = Hraw & keep;
+                            uint32_t x = lane_get(X, e);
+                            {
+                                // ---- states left to the general code: a scan could reach probe 32 (32 hit-free lanes in
+                                // a row, or the misses carried in plus those before the first hit)
+                                const uint32_t lead = ((x >> 7) & 1u) ? 63u - e : ((x >> 10) & 63u) - e;
+                                const uint32_t lead_bad = (c_in ^ 1u) & (sc_in + lead > 31 ? 1u : 0u);
+                                if (__builtin_expect(((farmask & keep) != 0) | (lead_bad != 0), 0)) {  // (P2, chain2, sc2 are this very state)
+                                    hold_fast = true;
+                                    quit = 1;
+                                    break;
+                                }
+                            }
+                            // ---- the serial part: one v_readlane per element; the last one is the exit state
+                            // (eight steps at a time, no branch in between: s_lshl_b64 and v_readlane use bits 0..5 of their
+                            // lane operand; two wait states more before a v_readlane may select by what the one before read)
+                            uint64_t S = 1ull << e;
                             do {
-                                S |= 1ull << jj;
-                                jj = lane_get(vJ, jj);
-                            } while (jj < 64);
+                                uint64_t bit;
+                                asm volatile(
+                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
+                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
+                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
+                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
+                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
+                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
+                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
+                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1"
+                                    : "+s"(S), "+s"(x), "=&s"(bit)
+                                    : "v"(X));
+                            } while (!(x & 64u));
+                            const uint32_t s_l = x & 63u;  // the last start: the lane whose jump left the tile
                             uint64_t V, Hp, C;
                             uint32_t ll, emit2;
-                            auto exit_for = [&](uint32_t lim) {
-                                const uint64_t bl = lanes_below(lim);
-                                const uint64_t Hm_t = Hm & bl, Sx = S & bl;
-                                const uint32_t s_l = 63u - (uint32_t)__builtin_clzll(Sx);  // (lane e is in Sx)
-                                const uint64_t Hx = Hm_t >> s_l;
-                                const uint32_t open = Hx == 0 ? 1u : 0u;  // the literal / scan is still open at lim
-                                Hp = Hm_t & ~(Hm_t - Sx);  // first hit of every segment [start, next start)
-                                const uint64_t bitlim = lim < 64 ? 1ull << lim : 0ull;
-                                V = (((Hp << 1) | (open ? bitlim : 0ull)) - Sx) & bl;
-                                const uint32_t jx = (s_l + ctz64(Hx | (1ull << 63))) & 63u;  // the last hit on the path
-                                const uint32_t mj = lane_get(tmlw, jx);
-                                const uint32_t carried = (Sx == (1ull << e) ? 1u : 0u) & (c_in ^ 1u);
-                                const uint32_t is_long = (open ^ 1u) & (mj == 64 ? 1u : 0u);
-                                const uint32_t pend = base + jx + mj;  // where the last copy ends
-                                chain2 = open ^ 1u;
-                                ll = is_long ? jx : 64u;
-                                P2 = open ? base + lim : (is_long ? base + jx : pend);
-                                sc2 = open ? (carried ? sc_in + lim - e : lim - s_l - 1) : 0u;
-                                emit2 = open ? (carried ? next_emit : base + s_l) : pend;
-                                pm1_done = (open ^ 1u) & (is_long ^ 1u) & (lim == 64 ? 1u : 0u) & (jx + mj == 64 ? 1u : 0u);
-                                const uint64_t Ins = ((Sx & ~(1ull << e)) >> 1) | ((uint64_t)pm1_done << 63);
-                                C = V | Ins;
-                            };
-                            exit_for(64);
                             {
+                                const uint32_t y = lane_get(Y, s_l), z = lane_get(Z, s_l);
+                                const uint32_t open = (x >> 7) & 1u;
+                                const uint32_t carried = (s_l == e ? 1u : 0u) & (c_in ^ 1u) & open;  // the scan carried in found nothing
+                                P2 = y & 0x1ffffu;
+                                chain2 = (y >> 17) & 1u;
+                                pm1_done = (y >> 18) & 1u;
+                                sc2 = carried ? sc_in + 64u - e : (y >> 19) & 63u;
+                                emit2 = carried ? next_emit : z;
+                                ll = ((x >> 8) & 1u) ? (x >> 10) & 63u : 64u;
+                                Hp = Hm & ~(Hm - S);  // first hit of every segment [start, next start)
+                                V = (Hp << 1) - S;    // [start, hit] of every segment; an open last one runs to lane 63
+                                C = V | ((S & ~(1ull << e)) >> 1) | ((uint64_t)pm1_done << 63);  // + the lane before each chain probe
+                            }
+                            {
+                                // two inserted lanes of one bucket: the visit ends before the second one
                                 const bool inC = __builtin_amdgcn_inverse_ballot_w64(C);
-                                uint32_t w = pos & 0xffffu;
-                                if (inC) {
-                                    tab.put(th, pos);
-                                    asm volatile("" ::: "memory");  // read back from LDS, not from `pos`
-                                    w = tab.get(th);
+                                const uint64_t conf = ballot64(inC && ((Glo & (uint32_t)C) | (Ghi & (uint32_t)(C >> 32))) != 0);
+                                if (__builtin_expect(conf != 0, 0)) {
+                                    // the same exit for a visit that ends before lane `cut`: the last start below it, and
+                                    // either its hit lies below the cut too (then nothing changes for it) or the scan is open there
+                                    const uint32_t cut = ctz64(conf);
+                                    poisoned = poisoned || cut <= e;  // (cannot happen: lane e has no earlier lane in C)
+                                    const uint64_t bl = below63(cut);
+                                    const uint64_t Sx = S & bl, Hm_t = Hm & bl;
+                                    const uint32_t sl = 63u - (uint32_t)__builtin_clzll(Sx | 1ull);
+                                    const uint32_t xs = lane_get(X, sl);
+                                    const uint32_t open = ((xs >> 7) & 1u) | (((xs >> 10) & 63u) >= cut ? 1u : 0u);
+                                    const uint32_t carried = (sl == e ? 1u : 0u) & (c_in ^ 1u) & open;
+                                    const uint32_t y = lane_get(Y, sl), z = lane_get(Z, sl);
+                                    P2 = open ? base + cut : y & 0x1ffffu;
+                                    chain2 = open ^ 1u;
+                                    pm1_done = 0;
+                                    sc2 = open ? (carried ? sc_in + cut - e : cut - sl - 1u) : 0u;
+                                    emit2 = open ? (carried ? next_emit : base + sl) : z;
+                                    ll = (!open && ((xs >> 8) & 1u)) ? (xs >> 10) & 63u : 64u;
+                                    Hp = Hm_t & ~(Hm_t - Sx);
+                                    V = (((Hp << 1) | (open ? 1ull << cut : 0ull)) - Sx) & bl;
+                                    C = V | ((Sx & ~(1ull << e)) >> 1);
                                 }
-                                uint64_t L = ballot64(inC && w != (pos & 0xffffu));
-                                if (__builtin_expect(L != 0, 0)) {  // two inserted lanes share a bucket: end the visit before the second one
-                                    asm volatile("" ::: "memory");
-                                    if (inC)
-                                        tab.put(th, tcand);  // roll back (lanes of one bucket hold the same old entry)
-                                    uint32_t cut = 64;
-                                    while (L) {
-                                        const uint32_t hv = lane_get(th, ctz64(L));
-                                        const uint64_t G = ballot64(inC && th == hv);
-                                        L &= ~G;
-                                        const uint64_t G2 = G & (G - 1);
-                                        const uint32_t second = ctz64(G2);
-                                        cut = second < cut ? second : cut;
-                                    }
-                                    const bool bad_cut = cut <= e || cut >= 64;
-                                    poisoned = poisoned || bad_cut;
-                                    exit_for(bad_cut ? e + 1 : cut);
-                                    if (__builtin_amdgcn_inverse_ballot_w64(C))
-                                        tab.put(th, pos);  // lanes below a cut share no bucket
-                                    UNIFORM_JOIN();
-                                }
+                                if (__builtin_amdgcn_inverse_ballot_w64(C))
+                                    tab.put(th, pos);  // (the lanes of C share no bucket now)
+                                UNIFORM_JOIN();
+                                Cacc |= C;
                             }
                             next_emit = emit2;
                             Vacc |= V;
@@ -954,21 +1075,26 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             long_lane = ll;  // (64: none)
                             if (__builtin_expect(poisoned | (ll < 64) | ((P2 >> 6) != t), 1))
                                 break;
-                            // the same tile again (after a cut): insert P-1, then give the lanes whose bucket
-                            // was written since their lookup the new candidate
+                            // the same tile again (after a cut): insert P-1, then the lanes whose bucket this turn has
+                            // written get the last writer as their candidate (known from the masks: no table access)
                             const uint32_t e2s = P2 & 63u;
-                            if (chain2 && lane == e2s - 1)
-                                tab.put(th, pos);
-                            asm volatile("" ::: "memory");
-                            const uint32_t cn = tab.get(th);
-                            const uint64_t st = ballot64(cn != tcand) & ~below63(e2s);
-                            if (st)
-                                patch(st, cn);
+                            if (chain2) {
+                                if (lane == e2s - 1)
+                                    tab.put(th, pos);
+                                UNIFORM_JOIN();
+                                Cacc |= 1ull << ((e2s - 1) & 63u);
+                            }
+                            {
+                                const uint32_t mlo = Glo & (uint32_t)Cacc, mhi = Ghi & (uint32_t)(Cacc >> 32);
+                                const uint32_t topl = mhi ? 63u - (uint32_t)__builtin_clz(mhi) : 31u - (uint32_t)__builtin_clz(mlo | 1u);
+                                newc = base + topl;
+                                sel = ballot64((mlo | mhi) != 0 && newc != tcand) & ~below63(e2s);
+                            }
                             e = e2s;
                             c_in = chain2;
                             sc_in = sc2;
                         }
-                        TRACE(4);
+                        TRACE(4); MARK("T4");
                         // ---- a match that runs past its 32 local bytes: its end is the next state
                         uint32_t Lip = 0, Lcnd = 0, Lm = 0;
                         const bool has_long = long_lane < 64;
@@ -982,14 +1108,14 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             sc2 = 0;
                             pm1_done = 0;
                         }
-                        TRACE(5);
+                        TRACE(5); MARK("T5");
                         // ---- the token goes on (or stays: the block's tail, a state for the general code, poison)
                         const bool cont = !((quit != 0) | poisoned | (P2 + kFastMargin > ip_limit));
                         if (cont)
                             team_publish(team.ptok, team_pack_parse(myturn + 1, P2, chain2, sc2, pm1_done, next_emit));
                         if (SZ_TEAM_PRIO)
                             __builtin_amdgcn_s_setprio(0);
-                        TRACE(6);
+                        TRACE(6); MARK("T6");
                         // ---- element writer of this tile: where do its elements begin?
                         if (!own_op) {
                             bool lost;
@@ -998,7 +1124,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             poisoned = poisoned || lost || (((uint32_t)ot >> 17) & 1u);
                             own_op = true;
                         }
-                        TRACE(7);
+                        TRACE(7); MARK("T7");
                         if (__builtin_expect(Hpacc != 0, 1)) {
                             const uint32_t jfirst = ctz64(Hpacc);
                             const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hpacc);
@@ -1049,7 +1175,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         }
                         if (__builtin_expect(has_long, 0))
                             op = emit_copy(out, op, Lip - Lcnd, Lm, lane);
-                        TRACE(8);
+                        TRACE(8); MARK("T8");
                         if (!cont) {  // this wave goes on alone (general code below, or the end of the block)
                             P = P2;
                             chain = chain2 != 0;
@@ -1060,15 +1186,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         own_op = false;
                         holder = false;
                         myturn += kTeamW;
-                        // ---- head of this wave's next tile, ahead of its token: the next wave takes the tile of P2
-                        const uint32_t tnext = (P2 >> 6) + (kTeamW - 1);
-                        if ((tnext << 6) + kFastMargin <= ip_limit) {
-                            head(tnext);
-                            ncand = tab.get(nh);
-                            head_loads();
-                            have_spec = true;
-                        }
-                        TRACE(9);
+                        // ---- this wave's next tile, if the parse goes on tile by tile: the next wave takes the tile of P2
+                        thead = (P2 >> 6) + (kTeamW - 1);
+                        need_head = (thead << 6) + kFastMargin <= ip_limit;
+                        TRACE(9); MARK("T9");
                     }
                     if (team_gone)
                         break;
@@ -2105,49 +2226,91 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
 }
 
 // Team kernel (round 3): workgroups of kTeamWaves wavefronts that compress ONE block together, sharing one
-// hash table in LDS (see "wave teams" above); four workgroups per CU, persistent grid over one device-wide
-// block counter.  No table in global memory: every lookup stays inside the CU.
+// hash table in LDS (see "wave teams" above), plus -- HYBRID -- kLoneWaves wavefronts that compress blocks of
+// their own with their table in global memory (the multi-wave kernel's extra waves); four workgroups per CU,
+// persistent grid over one device-wide block counter.  A team is through a block ~2.5 x sooner than a lone wave
+// and uses the CU's four LDS tables accordingly better; the lone waves fill the issue slots the teams leave
+// (a team's waves wait for their token a third of the time).
 #ifndef SZ_TEAM_WAVES
-#define SZ_TEAM_WAVES 0  // 0: the multi-wave kernel above takes compressible launches; 2..4: this kernel does
+#define SZ_TEAM_WAVES 2  // waves of a team (2..4)
+#endif
+#ifndef SZ_LONE_WAVES
+#define SZ_LONE_WAVES 2  // global-table waves beside the team in each workgroup (0..2)
 #endif
 static constexpr int kTeamWaves = SZ_TEAM_WAVES > 1 ? SZ_TEAM_WAVES : 2;
-__global__ __launch_bounds__(64 * kTeamWaves) __attribute__((amdgpu_waves_per_eu(kTeamWaves, kTeamWaves))) void compress_blocks_team_kernel(
+static constexpr int kLoneWaves = SZ_LONE_WAVES;
+static constexpr int kHybridWaves = kTeamWaves + kLoneWaves;
+static constexpr int kHybridPerSimd = kHybridWaves;  // four workgroups per CU, one wave of each per SIMD
+__global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_eu(kHybridPerSimd, kHybridPerSimd))) void compress_blocks_team_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
-    uint32_t *__restrict__ out_len, uint32_t flags, uint32_t *__restrict__ select,
+    uint32_t *__restrict__ out_len, uint32_t flags, uint16_t *scratch_tables, uint32_t *__restrict__ select,
     const uint32_t *__restrict__ queue, uint32_t auto_mode)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
     __shared__ __attribute__((aligned(16))) uint64_t tokens[2];
-    __shared__ uint32_t next_block;
+    __shared__ __attribute__((aligned(16))) uint8_t dup_scr[kTeamWaves * 256];
+    __shared__ uint32_t lone_bm[(kLoneWaves > 0 ? kLoneWaves : 1) * 512];  // one 16384-bit bitmap per global-table wave
+    __shared__ uint32_t next_block, team_bar;
     if (auto_mode && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
         return;
     const uint32_t n_work = queue ? uni(select[3]) : n_blocks;
-    if (blockIdx.x >= n_work)
+    if (blockIdx.x * (1u + kLoneWaves) >= n_work)
         return;
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    const HashTab<true> tab{lds_tab, nullptr, nullptr};
-    WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr};
-    for (;;) {
-        if (wave == 0) {  // one queue for the whole grid (address through VGPRs: see the multi-wave kernel)
-            uint32_t b0 = 0;
-            if (lane == 0) {
-                uint64_t qa = (uint64_t)(uintptr_t)(select + 2);
-                uint32_t qlo = (uint32_t)qa, qhi = (uint32_t)(qa >> 32);
-                asm volatile("" : "+v"(qlo), "+v"(qhi));
-                b0 = atomicAdd(reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)qhi << 32) | qlo)), 1u);
+    auto next_index = [&]() -> uint32_t {  // one queue for the whole grid (address through VGPRs: see the multi-wave kernel)
+        uint32_t b0 = 0;
+        if (lane == 0) {
+            uint64_t qa = (uint64_t)(uintptr_t)(select + 2);
+            uint32_t qlo = (uint32_t)qa, qhi = (uint32_t)(qa >> 32);
+            asm volatile("" : "+v"(qlo), "+v"(qhi));
+            b0 = atomicAdd(reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)qhi << 32) | qlo)), 1u);
+        }
+        return uni(b0);
+    };
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&team_bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();  // (the only workgroup-wide barrier: before the waves part ways)
+    if (kLoneWaves > 0 && wave >= kTeamWaves) {
+        // ---- a lone wave: blocks of its own, table in global memory (as the multi-wave kernel's extra waves)
+        const uint32_t lw = wave - kTeamWaves;
+        for (uint32_t i = lane; i < 512; i += 64)
+            lone_bm[lw * 512u + i] = 0;
+        uint16_t *my_glob = scratch_tables + (size_t)(blockIdx.x * (kLoneWaves > 0 ? kLoneWaves : 1) + lw) * kMaxTable;
+        const HashTab<false> gtab{nullptr, my_glob, lone_bm + lw * 512u};
+        for (;;) {
+            uint32_t b = next_index();
+            if (b >= n_work)
+                break;
+            if (queue)
+                b = uni(queue[b]);
+            const uint32_t n = block_length(in_len, total_len, in_stride, b);
+            if (n > kMaxBlock) {
+                out_len[b] = 0xffffffffu;
+                continue;
             }
-            b0 = uni(b0);
+            const uint32_t op = compress_one_block<0, true>(gtab, src + (uint64_t)b * in_stride, n,
+                                                            dst + (uint64_t)b * dst_stride, flags, lane);
+            out_len[b] = op;
+        }
+        return;
+    }
+    const HashTab<true> tab{lds_tab, nullptr, nullptr};
+    WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr, dup_scr + wave * 256u, &team_bar};
+    __builtin_amdgcn_s_setprio(1);  // (a team's waves go before the lone ones; the token's holder before both)
+    for (;;) {
+        if (wave == 0) {
+            const uint32_t b0 = next_index();
             __hip_atomic_store(&next_block, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __syncthreads();  // every wave of the team is past the block before (it left on the "done" token)
+        team_barrier<kTeamWaves>(&team_bar, lane);  // every wave of the team is past the block before (it left on the "done" token)
         uint32_t b = uni(__hip_atomic_load(&next_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (wave == 0) {  // only now: a wave still polling for "done" must not find an empty token instead
             __hip_atomic_store(&tokens[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&tokens[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __syncthreads();  // (everyone has the index and sees fresh tokens before any wave goes on)
+        team_barrier<kTeamWaves>(&team_bar, lane);  // (everyone has the index and sees fresh tokens before any wave goes on)
         if (b >= n_work)
             break;
         if (queue)
@@ -2229,15 +2392,15 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
                            dual->queue, dual->select);
     if (dual_ok) {
         // enough blocks to keep kGroupWaves waves per SIMD busy on every CU: persistent grid
-#if SZ_TEAM_WAVES > 1
-        {
-            const uint32_t tgrid = n_blocks < dual->n_slots ? n_blocks : dual->n_slots;
-            hipLaunchKernelGGL(compress_blocks_team_kernel, dim3(tgrid), dim3(64 * kTeamWaves), 0, stream, src, in_stride,
-                               d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->select,
+        if (dual->kernel == kKernelTeam) {
+            uint32_t tgrid = (n_blocks + kLoneWaves) / (1u + kLoneWaves);
+            tgrid = tgrid < dual->n_slots ? tgrid : dual->n_slots;
+            static_assert(kLoneWaves <= (int)kDualTablesPerGroup, "the workspace has kDualTablesPerGroup tables per workgroup");
+            hipLaunchKernelGGL(compress_blocks_team_kernel, dim3(tgrid), dim3(64 * kHybridWaves), 0, stream, src, in_stride,
+                               d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->tables, dual->select,
                                route ? dual->queue : (const uint32_t *)nullptr, sampled ? 1u : 0u);
             return hipGetLastError();
         }
-#endif
         uint32_t grid = (n_blocks + kGroupWaves - 1) / kGroupWaves;
         grid = grid < dual->n_slots ? grid : dual->n_slots;
         hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(64 * kGroupWaves), 0, stream, src, in_stride,

@@ -21,7 +21,9 @@ struct DualScratch {
     uint32_t n_slots;
     uint32_t min_blocks;  // launches with fewer blocks use the single kernel
     uint32_t mode;        // kDualAuto: single/dual per launch from a data sample; kDualRoute: per block
+    uint32_t kernel;      // which kernel takes the compressible launches: kKernelMulti or kKernelTeam
 };
+enum CompressibleKernel : uint32_t { kKernelMulti = 0, kKernelTeam = 1 };
 constexpr size_t kDualTableBytes = 16384 * 2;
 constexpr uint32_t kDualQueueEntries = 1u << 20;  // 4 MiB: 64 GiB of 64 KiB blocks per launch
 #ifndef SZ_GROUP_WAVES

@@ -182,4 +182,4 @@ def test_parse_state_of_the_compress_kernels_is_provably_wave_uniform(tmp_path):
         assert not bad, "%s: loops left through a per-lane branch:\n%s" % (name, "\n".join(bad))
         div = [l.strip()[:120] for l in fn.splitlines() if state.search(l)]
         assert not div, "%s: parse state the compiler cannot prove uniform:\n%s" % (name, "\n".join(div[:10]))
-    assert seen == 3
+    assert seen == 4  # single, multi-wave, team, small-blocks

@@ -26,7 +26,7 @@ def sha(b):
 
 # ------------------------------------------------------------------ host-buffer API
 
-@pytest.mark.parametrize("mode", ["auto", "dual"])
+@pytest.mark.parametrize("mode", ["auto", "team", "dual"])
 def test_host_compress_is_snappy_compress(mode, monkeypatch):
     if mode != "auto":
         monkeypatch.setenv("SZ_KERNEL", mode)  # ragged last fragment through the multi-wave kernel too
@@ -242,7 +242,7 @@ def _full_size_round_trip(kind, n_blocks, expect_len=None):
     return lens
 
 
-@pytest.mark.parametrize("mode", ["single", "dual", "route"])
+@pytest.mark.parametrize("mode", ["single", "team", "dual", "route"])
 def test_full_size_forced_kernels(mode, monkeypatch):
     """The two compress kernels at full size on every workload (auto mode picks one per launch), and
     the per-block routing between them inside one launch (route: the mix holds both classes)."""
@@ -281,14 +281,16 @@ def test_routing_a_compressible_minority_inside_an_incompressible_launch(monkeyp
     parity_util.assert_all_blocks_match_oracle(src, dst, out_len, nb, P.SLOT_STRIDE, what="routed launch")
 
 
-def test_global_tables_are_clean_for_every_block(monkeypatch):
-    """The multi-wave kernel's extra waves keep their tables in global memory and zero them per block:
+@pytest.mark.parametrize("mode", ["dual", "team"])
+def test_global_tables_are_clean_for_every_block(mode, monkeypatch):
+    """The multi-wave kernel's extra waves (and the team kernel's lone waves) keep their tables in global memory and zero them per block;
+    the team kernel's teams reuse one LDS table, two tokens and a barrier counter block after block:
     nothing of one block (or one launch) may leak into the next.  Same two blocks, several hundred
     launches through the same table slots; then blocks of different sizes (different table sizes)
     alternating through one slot; then the launch that hung experimental builds (incompressible blocks
     only)."""
     import torch
-    monkeypatch.setenv("SZ_KERNEL", "dual")
+    monkeypatch.setenv("SZ_KERNEL", mode)
     P = pkg()
     blocks = [fuzzgen.gen("text_mtg", 31337 + i, 65536).tobytes() for i in range(2)]
     want = [oracle_lib.raw_compress(b) for b in blocks]

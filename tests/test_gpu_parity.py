@@ -14,11 +14,12 @@ from gpu_util import compress_many, pkg
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "single", "dual"], autouse=True)
+@pytest.fixture(params=["auto", "single", "team", "dual"], autouse=True)
 def kernel_mode(request, monkeypatch):
-    """Every parity test runs through both compress kernels: `single` (one wave per SIMD, LDS
-    table) and `dual` (three waves per SIMD, two of them with their tables in global
-    memory), plus the default data-sampled choice.  The library reads SZ_KERNEL on every call."""
+    """Every parity test runs through every compress kernel: `single` (one wave per SIMD, LDS table),
+    `team` (two waves share a block and its LDS table, parse token in LDS, + two global-table waves per
+    workgroup: round 3's kernel for compressible launches) and `dual` (rounds 1-2's multi-wave kernel: three
+    independent waves per SIMD), plus the default data-sampled choice.  The library reads SZ_KERNEL on every call."""
     if request.param == "auto":
         monkeypatch.delenv("SZ_KERNEL", raising=False)
     else:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/soak.py -- long differential run of the GPU compressor against the oracle (GPU box).
-usage: soak.py [n_cases] [seed]   -- every case through the single and the multi-wave kernel."""
+usage: soak.py [n_cases] [seed]   -- every case through the single, the team and the multi-wave kernel."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -23,7 +23,7 @@ while done < n_cases:
         cases.append((kind, seed0 + done + i, n))
     blocks = [fuzzgen.gen(k, s, n).tobytes() for k, s, n in cases]
     want = [oracle_lib.raw_compress(b) for b in blocks]
-    for mode in ("single", "dual"):
+    for mode in ("single", "team", "dual"):
         os.environ["SZ_KERNEL"] = mode
         got = compress_many(blocks)
         for c, g, w in zip(cases, got, want):
@@ -48,5 +48,5 @@ while done < n_cases:
             print("DECOMPRESS MISMATCH", cases[i], int(stt[i]), int(ul[i]), flush=True)
     done += len(cases)
     print("%d cases, %d mismatches, %.0f s" % (done, bad, time.time() - t0), flush=True)
-print("soak done: %d cases x 2 kernels, %d mismatches" % (done, bad))
+print("soak done: %d cases x 3 kernels, %d mismatches" % (done, bad))
 sys.exit(1 if bad else 0)

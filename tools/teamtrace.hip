@@ -44,8 +44,8 @@ int main(int argc, char **argv)
     }
     if (hipMemcpy(tr.data(), d_tr, ntr * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
     // per block: stamps by turn
-    const char *ph[10] = {"wait", "token", "entered", "compared", "visited", "long", "published", "op", "written", "head"};
-    double seg[10] = {0}, handoff = 0, period = 0, opwait = 0, idle = 0, busy = 0; unsigned long long nturn = 0, nper = 0;
+    const char *ph[11] = {"trip", "token", "checked", "patched", "visited", "long", "published", "op", "written", "end", "headed"};
+    double seg[11] = {0}, handoff = 0, period = 0, opwait = 0, idle = 0, busy = 0, headt = 0; unsigned long long nturn = 0, nper = 0;
     for (uint32_t b = 0; b < szk::kTraceBlocks && b < nb; b++) {
         std::map<uint32_t, std::vector<long long>> turns;  // turn -> time of phase 0..9 (-1: none)
         std::map<uint32_t, int> who;
@@ -57,7 +57,7 @@ int main(int argc, char **argv)
                 // a stamp 0 ("starts waiting") carries the turn the wave waits for; 9 carries the turn + W it goes to next
                 uint32_t key = id == 9 ? turn - W : turn;
                 auto &v = turns[key];
-                if (v.empty()) v.assign(10, -1);
+                if (v.empty()) v.assign(11, -1);
                 if (v[id] < 0) v[id] = t;
                 who[key] = w;
             }
@@ -74,13 +74,14 @@ int main(int argc, char **argv)
             if (v[7] >= 0) opwait += v[7] - v[6];
             if (v[8] >= 0 && v[7] >= 0) seg[8] += v[8] - v[7];
             if (v[9] >= 0 && v[8] >= 0) seg[9] += v[9] - v[8];
-            if (v[0] >= 0) idle += v[1] - v[0];
+            if (v[10] >= 0) idle += v[1] - v[10];
             if (v[9] >= 0) busy += v[9] - v[1];
+            if (v[10] >= 0 && v[0] >= 0) headt += v[10] - v[0];
             if (prev && (*prev)[6] >= 0) { handoff += v[1] - (*prev)[6]; period += v[1] - (*prev)[1]; nper++; }
             if (b == 0 && listed < list && kv.first >= 40) {
                 printf("  turn %5u wave %d  token@%7lld", kv.first, who[kv.first], v[1] - t00);
                 for (int i = 2; i <= 9; i++) printf("  %s +%lld", ph[i], v[i] < 0 ? -1 : v[i] - v[1]);
-                printf("  (waited %lld)\n", v[0] < 0 ? -1 : v[1] - v[0]);
+                printf("  (head %lld, waited %lld)\n", v[0] < 0 || v[10] < 0 ? -1 : v[10] - v[0], v[10] < 0 ? -1 : v[1] - v[10]);
                 listed++;
             }
             prev = &v;
@@ -89,13 +90,13 @@ int main(int argc, char **argv)
     if (!nturn) { printf("no stamps\n"); return 0; }
     printf("%llu traced turns; per turn (ticks):\n", nturn);
     printf("  period token -> next wave's token   %8.1f  (over %llu consecutive pairs)\n", period / nper, nper);
-    printf("    enter (stale check / head)        %8.1f\n", seg[2] / nturn);
-    printf("    compare + patch                   %8.1f\n", seg[3] / nturn);
+    printf("    P-1, lookups checked              %8.1f\n", seg[2] / nturn);
+    printf("    patch (first visit)               %8.1f\n", seg[3] / nturn);
     printf("    visits (walk, exit, commit)       %8.1f\n", seg[4] / nturn);
     printf("    long match length                 %8.1f\n", seg[5] / nturn);
     printf("    publish                           %8.1f\n", seg[6] / nturn);
     printf("    hand-off (published -> acquired)  %8.1f\n", handoff / nper);
-    printf("  off the chain: wait for op %8.1f, element writer %8.1f, op publish + next head %8.1f\n", opwait / nturn, seg[8] / nturn, seg[9] / nturn);
+    printf("  off the chain: wait for op %8.1f, element writer %8.1f, op publish %8.1f, head of the next tile %8.1f\n", opwait / nturn, seg[8] / nturn, seg[9] / nturn, headt / nturn);
     printf("  a wave per turn of its own: busy %8.1f, waiting for the token %8.1f\n", busy / nturn, idle / nturn);
     return 0;
 }
