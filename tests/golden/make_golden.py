@@ -21,6 +21,8 @@ What is written:
                               per-64KiB-block RawCompress lengths/sha256 for the big corpora
   golden_fuzz.json            (kind, seed, n) -> length + sha256 of RawCompress output for the
                               deterministic generators in tests/fuzzgen.py
+  hw_results_sizes.json       the compressed-length column of the reference's benchmark/hw_results.csv
+                              (the accelerator's own sizes: SURVEY 8f-4, tests/hw_model.py)
   sw_results_sizes.json       the compressed-length column of the reference's
                               benchmark/sw_results.csv (the only numbers the reference itself
                               pins for this path)
@@ -118,6 +120,19 @@ def main():
             rows.append({"type": t, "length": int(length), "compressed_length": int(clen)})
     with open(os.path.join(HERE, "sw_results_sizes.json"), "w") as f:
         json.dump({"source": "reference benchmark/sw_results.csv (type;length;cycles;compressed-length)",
+                   "file_prefix": {"random": "random", "real": "real", "repeat": "repeating"},
+                   "rows": rows}, f, indent=1)
+
+    # ---- the accelerator's own sizes (tests/hw_model.py, tests/test_hw_model.py)
+    rows = []
+    with open(os.path.join(REF, "benchmark", "hw_results.csv")) as f:
+        header = f.readline().strip()
+        assert header == "type;length;cycles;compressed-length", header
+        for line in f:
+            t, length, _cycles, clen = line.strip().split(";")
+            rows.append({"type": t, "length": int(length), "compressed_length": int(clen)})
+    with open(os.path.join(HERE, "hw_results_sizes.json"), "w") as f:
+        json.dump({"source": "reference benchmark/hw_results.csv (type;length;cycles;compressed-length): the accelerator's own output sizes, 512-entry table",
                    "file_prefix": {"random": "random", "real": "real", "repeat": "repeating"},
                    "rows": rows}, f, indent=1)
 
