@@ -486,19 +486,27 @@ __device__ __forceinline__ void team_barrier(uint32_t *bar, uint32_t lane)
     asm volatile("" ::: "memory");
 }
 
-// waits until the token in `slot` carries `turn` (or "done"); returns the token, or 0 with *lost = true
-__device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t turn, bool &lost)
+// waits until the token in `slot` carries `turn` (or "done"); returns the token; lost = 1: gave up
+__device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t turn, uint32_t &lost)
 {
+    // (flags are integers and every value is brought back to scalar registers at once: a boolean that the
+    // compiler keeps as a lane mask, or a counter it keeps in a vector register, costs the loop a round trip
+    // between the vector and the scalar unit per poll -- ~25 clocks each, tools/isacost.hip)
     uint64_t v = 0;
-    lost = false;
-    for (uint32_t spin = 0;; spin++) {
+    uint32_t spin = 0;
+    lost = 0;
+    for (;;) {
         v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        v = ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
-        const uint32_t tt = (uint32_t)(v >> 42);
-        if (tt == turn || tt == kTeamDoneTurn)
+        const uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+        v = ((uint64_t)hi << 32) | lo;
+        const uint32_t tt = hi >> 10;
+        if (tt == turn)
             break;
-        if (spin >= SZ_TEAM_SPIN_CAP) {
-            lost = true;
+        if (tt == kTeamDoneTurn)
+            break;
+        spin = uni(spin + 1u);
+        if (spin > SZ_TEAM_SPIN_CAP) {
+            lost = 1;
             break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -774,7 +782,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     // buckets) is made in ONE place, at the top of the turn loop: ahead of the token for the tile this
                     // wave expects next, or -- the parse went elsewhere, or this wave comes from the general code -- with
                     // the token in hand for the tile of P2.
-                    bool have_head = false, need_head = holder;
+                    uint32_t have_head = 0, need_head = holder ? 1u : 0u;  // (flags as integers: see team_wait)
+                    uint32_t tpois = 0;  // poison met inside this path (folded into `poisoned` where the path is left)
                     uint32_t thead = P >> 6;
                     uint32_t P2 = P, sc2 = 0, chain2 = 1, pm1_done = 0, quit = 0;
                     const uint32_t lb_lo = lane < 32 ? (1u << lane) - 1u : 0xffffffffu;  // bits of the lanes below this one
@@ -827,7 +836,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     for (;;) {  // ================================================ one turn per trip
                         P2 = uni(P2); sc2 = uni(sc2); chain2 = uni(chain2); pm1_done = uni(pm1_done); quit = uni(quit);
                         holder = unib(holder); own_op = unib(own_op); myturn = uni(myturn); next_emit = uni(next_emit);
-                        op = uni(op); poisoned = unib(poisoned); have_head = unib(have_head); need_head = unib(need_head);
+                        op = uni(op); tpois = uni(tpois); have_head = uni(have_head); need_head = uni(need_head);
                         t = uni(t); thead = uni(thead); tb_base = uni(tb_base); tb_tile = uni(tb_tile); tn_tile = uni(tn_tile);
                         TRACE(0); MARK("T0");
                         if (need_head) {
@@ -899,16 +908,16 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                 tmlw = ml == 32 ? 64u : ml;
                             }
                             jumps();
-                            have_head = true;
-                            need_head = false;
+                            have_head = 1;
+                            need_head = 0;
                         }
                         TRACE(10); MARK("T10");
                         if (!holder) {
-                            bool lost;
+                            uint32_t lost;
                             const uint64_t tok = team_wait(team.ptok, myturn, lost);
-                            if (lost || (uint32_t)(tok >> 42) == kTeamDoneTurn) {
+                            if ((lost | ((uint32_t)(tok >> 42) == kTeamDoneTurn ? 1u : 0u)) != 0) {
                                 team_gone = true;
-                                team_lost = lost;
+                                team_lost = lost != 0;
                                 break;
                             }
                             P2 = (uint32_t)tok & 0x1ffffu;
@@ -923,13 +932,13 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             __builtin_amdgcn_s_setprio(SZ_TEAM_PRIO);
                         // ---- enter the tile of P2
                         const uint32_t t2 = P2 >> 6, e2 = P2 & 63u;
-                        if (__builtin_expect(!(have_head && t2 == t), 0)) {  // not the tile this wave has a head of: make it now
+                        if (__builtin_expect(((have_head ^ 1u) | (t2 ^ t)) != 0, 0)) {  // not the tile this wave has a head of: make it now
                             thead = t2;
-                            need_head = true;
-                            have_head = false;
+                            need_head = 1;
+                            have_head = 0;
                             continue;
                         }
-                        have_head = false;
+                        have_head = 0;
                         const uint32_t acc_emit = next_emit;   // start of the literal that is open on entry (if any)
                         const bool acc_open = chain2 == 0;
                         const uint32_t base = t << 6;
@@ -937,13 +946,14 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         // The reference inserts P-1 before it looks P up; then the head's lookups are checked against the
                         // table as it stands now (the lanes the parse can still reach): a lane whose bucket was written
                         // since -- by the tiles in between, or by P-1 just now -- gets the new candidate.
-                        if (chain2 && !pm1_done) {
-                            if (e2 >= 1) {
-                                if (lane == e2 - 1)
-                                    tab.put(th, P2 - 1);
-                            } else if (lane == 0) {
-                                tab.put((ld32(in + P2 - 1) * kHashMul) >> shift, P2 - 1);
-                            }
+                        if ((chain2 & (pm1_done ^ 1u)) != 0) {
+                            // (every lane stores: lane e2 - 1 into its bucket, the others into a scratch halfword of this
+                            // wave's -- no EXEC mask to set up, i.e. no trip to the scalar unit and back)
+                            uint32_t hp = th;
+                            if (__builtin_expect(e2 == 0, 0))
+                                hp = (ld32(in + P2 - 1) * kHashMul) >> shift;
+                            uint16_t *slot = (lane == ((e2 - 1u) & 63u)) ? tab.lds + hp : reinterpret_cast<uint16_t *>(team.scr + 254);
+                            __hip_atomic_store(slot, (uint16_t)(P2 - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             asm volatile("" ::: "memory");
                         }
                         uint32_t newc = tab.get(th);
@@ -951,6 +961,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         TRACE(2); MARK("T2");
                         uint64_t Vacc = 0, Hpacc = 0;
                         uint64_t Cacc = 0;  // lanes of this tile whose table entry this turn has written
+                        uint32_t redo_head = 0;
                         uint32_t long_lane = 64;
                         e = e2;
                         c_in = chain2;
@@ -961,8 +972,18 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                 // no memory access on the token's path, unless a candidate lies before it), hit bit and match
                                 // length merged in, jumps redone
                                 const bool on = __builtin_amdgcn_inverse_ballot_w64(sel);
+                                if (__builtin_expect((ballot64(newc < tb_base) & sel) != 0, 0)) {
+                                    // a candidate that lies before the register buffer (the lookups were made long ago: this
+                                    // wave came back from the general code, or the parse jumped): a fresh head of this tile
+                                    // instead -- no memory access in the patch itself, so that nothing on the token's path ever
+                                    // waits for vector memory (a wait here would also wait for the prefetch of the next buffer)
+                                    thead = t;
+                                    need_head = 1;
+                                    redo_head = 1;
+                                    break;
+                                }
                                 u32x4 c, c2;
-                                if (__builtin_expect(ballot64(on && newc < tb_base) == 0, 1)) {
+                                {
                                     const uint32_t r = on ? newc - tb_base : 0u;  // (every lane takes part in the shuffles)
                                     const uint32_t i0 = (r >> 2) << 2, sh = r & 3u;
                                     uint32_t d[9];
@@ -977,15 +998,11 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                     c2.y = __builtin_amdgcn_alignbyte(d[6], d[5], sh);
                                     c2.z = __builtin_amdgcn_alignbyte(d[7], d[6], sh);
                                     c2.w = __builtin_amdgcn_alignbyte(d[8], d[7], sh);
-                                } else {
-                                    const uint32_t cc = on ? newc : 0u;
-                                    c = ld128(in + cc);
-                                    c2 = ld128(in + cc + 16);
                                 }
                                 const uint32_t ml = matchlen32(na, na2, c, c2);
                                 tcand = on ? newc : tcand;
                                 tmlw = on ? (ml == 32 ? 64u : ml) : tmlw;
-                                Hraw = (Hraw & ~sel) | ballot64(on && c.x == na.x);
+                                Hraw = (Hraw & ~sel) | (ballot64(c.x == na.x) & sel);
                                 jumps();
                             }
                             TRACE(3); MARK("T3");
@@ -995,16 +1012,18 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             {
                                 // ---- states left to the general code: a scan could reach probe 32 (32 hit-free lanes in
                                 // a row, or the misses carried in plus those before the first hit)
-                                const uint32_t lead = ((x >> 7) & 1u) ? 63u - e : ((x >> 10) & 63u) - e;
-                                const uint32_t lead_bad = (c_in ^ 1u) & (sc_in + lead > 31 ? 1u : 0u);
-                                if (__builtin_expect(((farmask & keep) != 0) | (lead_bad != 0), 0)) {  // (P2, chain2, sc2 are this very state)
+                                const uint32_t lead = (x & 0x80u) ? 63u - e : ((x >> 10) & 63u) - e;
+                                const uint32_t lead_bad = (c_in ^ 1u) & ((31u - (sc_in + lead)) >> 31);  // sc_in + lead > 31
+                                const uint64_t far = farmask & keep;
+                                if (__builtin_expect(((uint32_t)far | (uint32_t)(far >> 32) | lead_bad) != 0, 0)) {  // (P2, chain2, sc2 are this very state)
                                     hold_fast = true;
                                     quit = 1;
                                     break;
                                 }
                             }
+                            TRACE(11);
                             // ---- the serial part: one v_readlane per element; the last one is the exit state
-                            // (eight steps at a time, no branch in between: s_lshl_b64 and v_readlane use bits 0..5 of their
+                            // (four steps at a time, no branch in between: s_lshl_b64 and v_readlane use bits 0..5 of their
                             // lane operand; two wait states more before a v_readlane may select by what the one before read)
                             uint64_t S = 1ull << e;
                             do {
@@ -1013,67 +1032,67 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                     "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
                                     "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
                                     "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
-                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
-                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
-                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
-                                    "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
                                     "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1"
                                     : "+s"(S), "+s"(x), "=&s"(bit)
                                     : "v"(X));
                             } while (!(x & 64u));
+                            TRACE(12);
                             const uint32_t s_l = x & 63u;  // the last start: the lane whose jump left the tile
                             uint64_t V, Hp, C;
                             uint32_t ll, emit2;
                             {
                                 const uint32_t y = lane_get(Y, s_l), z = lane_get(Z, s_l);
                                 const uint32_t open = (x >> 7) & 1u;
-                                const uint32_t carried = (s_l == e ? 1u : 0u) & (c_in ^ 1u) & open;  // the scan carried in found nothing
+                                // the scan carried in found nothing: (s_l == e) as an integer, ((s_l ^ e) - 1) >> 31
+                                const uint32_t carried = (((s_l ^ e) - 1u) >> 31) & (c_in ^ 1u) & open;
                                 P2 = y & 0x1ffffu;
                                 chain2 = (y >> 17) & 1u;
                                 pm1_done = (y >> 18) & 1u;
                                 sc2 = carried ? sc_in + 64u - e : (y >> 19) & 63u;
                                 emit2 = carried ? next_emit : z;
-                                ll = ((x >> 8) & 1u) ? (x >> 10) & 63u : 64u;
+                                ll = (x & 0x100u) ? (x >> 10) & 63u : 64u;
                                 Hp = Hm & ~(Hm - S);  // first hit of every segment [start, next start)
                                 V = (Hp << 1) - S;    // [start, hit] of every segment; an open last one runs to lane 63
                                 C = V | ((S & ~(1ull << e)) >> 1) | ((uint64_t)pm1_done << 63);  // + the lane before each chain probe
                             }
+                            TRACE(13);
                             {
                                 // two inserted lanes of one bucket: the visit ends before the second one
-                                const bool inC = __builtin_amdgcn_inverse_ballot_w64(C);
-                                const uint64_t conf = ballot64(inC && ((Glo & (uint32_t)C) | (Ghi & (uint32_t)(C >> 32))) != 0);
+                                const uint64_t conf = ballot64(((Glo & (uint32_t)C) | (Ghi & (uint32_t)(C >> 32))) != 0) & C;
                                 if (__builtin_expect(conf != 0, 0)) {
                                     // the same exit for a visit that ends before lane `cut`: the last start below it, and
                                     // either its hit lies below the cut too (then nothing changes for it) or the scan is open there
                                     const uint32_t cut = ctz64(conf);
-                                    poisoned = poisoned || cut <= e;  // (cannot happen: lane e has no earlier lane in C)
+                                    tpois |= (e - cut) >> 31 ^ 1u;  // cut <= e (cannot happen: lane e has no earlier lane in C)
                                     const uint64_t bl = below63(cut);
                                     const uint64_t Sx = S & bl, Hm_t = Hm & bl;
                                     const uint32_t sl = 63u - (uint32_t)__builtin_clzll(Sx | 1ull);
                                     const uint32_t xs = lane_get(X, sl);
-                                    const uint32_t open = ((xs >> 7) & 1u) | (((xs >> 10) & 63u) >= cut ? 1u : 0u);
-                                    const uint32_t carried = (sl == e ? 1u : 0u) & (c_in ^ 1u) & open;
+                                    const uint32_t open = ((xs >> 7) & 1u) | ((((xs >> 10) & 63u) - cut) >> 31 ^ 1u);  // no hit, or it lies at or past the cut
+                                    const uint32_t carried = (((sl ^ e) - 1u) >> 31) & (c_in ^ 1u) & open;
                                     const uint32_t y = lane_get(Y, sl), z = lane_get(Z, sl);
                                     P2 = open ? base + cut : y & 0x1ffffu;
                                     chain2 = open ^ 1u;
                                     pm1_done = 0;
                                     sc2 = open ? (carried ? sc_in + cut - e : cut - sl - 1u) : 0u;
                                     emit2 = open ? (carried ? next_emit : base + sl) : z;
-                                    ll = (!open && ((xs >> 8) & 1u)) ? (xs >> 10) & 63u : 64u;
+                                    ll = ((open ^ 1u) & (xs >> 8) & 1u) ? (xs >> 10) & 63u : 64u;
                                     Hp = Hm_t & ~(Hm_t - Sx);
                                     V = (((Hp << 1) | (open ? 1ull << cut : 0ull)) - Sx) & bl;
                                     C = V | ((Sx & ~(1ull << e)) >> 1);
                                 }
+                                TRACE(14);
                                 if (__builtin_amdgcn_inverse_ballot_w64(C))
                                     tab.put(th, pos);  // (the lanes of C share no bucket now)
                                 UNIFORM_JOIN();
                                 Cacc |= C;
                             }
+                            TRACE(15);
                             next_emit = emit2;
                             Vacc |= V;
                             Hpacc |= Hp;
                             long_lane = ll;  // (64: none)
-                            if (__builtin_expect(poisoned | (ll < 64) | ((P2 >> 6) != t), 1))
+                            if (__builtin_expect((tpois | (ll ^ 64u) | ((P2 >> 6) ^ t)) != 0, 1))
                                 break;
                             // the same tile again (after a cut): insert P-1, then the lanes whose bucket this turn has
                             // written get the last writer as their candidate (known from the masks: no table access)
@@ -1088,17 +1107,19 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                 const uint32_t mlo = Glo & (uint32_t)Cacc, mhi = Ghi & (uint32_t)(Cacc >> 32);
                                 const uint32_t topl = mhi ? 63u - (uint32_t)__builtin_clz(mhi) : 31u - (uint32_t)__builtin_clz(mlo | 1u);
                                 newc = base + topl;
-                                sel = ballot64((mlo | mhi) != 0 && newc != tcand) & ~below63(e2s);
+                                sel = ballot64((mlo | mhi) != 0) & ballot64(newc != tcand) & ~below63(e2s);
                             }
                             e = e2s;
                             c_in = chain2;
                             sc_in = sc2;
                         }
+                        if (__builtin_expect(redo_head != 0, 0))  // (only ever on the first visit: nothing of this turn is committed yet)
+                            continue;
                         TRACE(4); MARK("T4");
                         // ---- a match that runs past its 32 local bytes: its end is the next state
                         uint32_t Lip = 0, Lcnd = 0, Lm = 0;
-                        const bool has_long = long_lane < 64;
-                        if (__builtin_expect(has_long, 0)) {
+                        const uint32_t has_long = long_lane ^ 64u;  // (non-zero: there is one)
+                        if (__builtin_expect(has_long != 0, 0)) {
                             Lip = base + long_lane;
                             Lcnd = lane_get(tcand, long_lane);
                             Lm = match_length<kMatchPieces>(in, Lcnd, Lip, n, lane, 32);
@@ -1110,7 +1131,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         }
                         TRACE(5); MARK("T5");
                         // ---- the token goes on (or stays: the block's tail, a state for the general code, poison)
-                        const bool cont = !((quit != 0) | poisoned | (P2 + kFastMargin > ip_limit));
+                        const uint32_t stop = quit | tpois | ((ip_limit - (P2 + kFastMargin)) >> 31);  // ... or P2 + kFastMargin > ip_limit
+                        const bool cont = stop == 0;
                         if (cont)
                             team_publish(team.ptok, team_pack_parse(myturn + 1, P2, chain2, sc2, pm1_done, next_emit));
                         if (SZ_TEAM_PRIO)
@@ -1118,10 +1140,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         TRACE(6); MARK("T6");
                         // ---- element writer of this tile: where do its elements begin?
                         if (!own_op) {
-                            bool lost;
+                            uint32_t lost;
                             const uint64_t ot = team_wait(team.otok, myturn, lost);
                             op = (uint32_t)ot & 0x1ffffu;
-                            poisoned = poisoned || lost || (((uint32_t)ot >> 17) & 1u);
+                            tpois |= lost | (((uint32_t)ot >> 17) & 1u);
                             own_op = true;
                         }
                         TRACE(7); MARK("T7");
@@ -1143,12 +1165,12 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                 if (lane < len)
                                     out[op + 1 + lane] = (uint8_t)lbyte;
                                 UNIFORM_JOIN();
-                                poisoned = poisoned || len > 60;
+                                tpois |= (60u - len) >> 31;  // len > 60
                                 op += 1 + len;
                                 Lit &= ~below63(jfirst);
                             }
                             const uint64_t RS = Lit & ~(Lit << 1);
-                            const uint64_t HC = has_long ? Hpacc & ~(1ull << long_lane) : Hpacc;
+                            const uint64_t HC = has_long ? Hpacc & ~(1ull << (long_lane & 63u)) : Hpacc;
                             const bool is_lit = __builtin_amdgcn_inverse_ballot_w64(Lit);
                             const bool run_start = __builtin_amdgcn_inverse_ballot_w64(RS);
                             const bool is_hit = __builtin_amdgcn_inverse_ballot_w64(HC);
@@ -1173,22 +1195,23 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             UNIFORM_JOIN();
                             op += lane_get(incl, 63);
                         }
-                        if (__builtin_expect(has_long, 0))
+                        if (__builtin_expect(has_long != 0, 0))
                             op = emit_copy(out, op, Lip - Lcnd, Lm, lane);
                         TRACE(8); MARK("T8");
                         if (!cont) {  // this wave goes on alone (general code below, or the end of the block)
+                            poisoned = poisoned || tpois != 0;
                             P = P2;
                             chain = chain2 != 0;
                             sc = sc2;
                             break;
                         }
-                        team_publish(team.otok, (uint64_t)(op | (poisoned ? 1u << 17 : 0u)) | ((uint64_t)(myturn + 1) << 42));
+                        team_publish(team.otok, (uint64_t)(op | (tpois << 17)) | ((uint64_t)(myturn + 1) << 42));
                         own_op = false;
                         holder = false;
                         myturn += kTeamW;
                         // ---- this wave's next tile, if the parse goes on tile by tile: the next wave takes the tile of P2
                         thead = (P2 >> 6) + (kTeamW - 1);
-                        need_head = (thead << 6) + kFastMargin <= ip_limit;
+                        need_head = ((ip_limit - ((thead << 6) + kFastMargin)) >> 31) ^ 1u;  // (thead << 6) + kFastMargin <= ip_limit
                         TRACE(9); MARK("T9");
                     }
                     if (team_gone)

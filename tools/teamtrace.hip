@@ -24,8 +24,8 @@ int main(int argc, char **argv)
     if (hipMalloc(&d_in, in.size()) != hipSuccess || hipMalloc(&d_out, (size_t)nb * 76544) != hipSuccess || hipMalloc(&d_len, nb * 4) != hipSuccess) return 2;
     if (hipMemcpy(d_in, in.data(), in.size(), hipMemcpyHostToDevice) != hipSuccess) return 2;
     szk::DualScratch sc{};
-    sc.n_slots = 1024; sc.min_blocks = 2; sc.mode = szk::kDualAlways;
-    if (hipMalloc(&sc.tables, 64) != hipSuccess || hipMalloc(&sc.select, 64) != hipSuccess || hipMemset(sc.select, 0, 64) != hipSuccess) return 2;
+    sc.n_slots = 1024; sc.min_blocks = 2; sc.mode = szk::kDualAlways; sc.kernel = szk::kKernelTeam;
+    if (hipMalloc(&sc.tables, (size_t)sc.n_slots * szk::kDualTablesPerGroup * szk::kDualTableBytes) != hipSuccess || hipMalloc(&sc.select, 64) != hipSuccess || hipMemset(sc.select, 0, 64) != hipSuccess) return 2;
     const int W = szk::kTeamWaves;
     const size_t ntr = (size_t)szk::kTraceBlocks * W * szk::kTraceCap;
     unsigned long long *d_tr;
@@ -45,7 +45,7 @@ int main(int argc, char **argv)
     if (hipMemcpy(tr.data(), d_tr, ntr * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
     // per block: stamps by turn
     const char *ph[11] = {"trip", "token", "checked", "patched", "visited", "long", "published", "op", "written", "end", "headed"};
-    double seg[11] = {0}, handoff = 0, period = 0, opwait = 0, idle = 0, busy = 0, headt = 0; unsigned long long nturn = 0, nper = 0;
+    double fine[5] = {0}; unsigned long long nfine = 0; double seg[11] = {0}, handoff = 0, period = 0, opwait = 0, idle = 0, busy = 0, headt = 0; unsigned long long nturn = 0, nper = 0;
     for (uint32_t b = 0; b < szk::kTraceBlocks && b < nb; b++) {
         std::map<uint32_t, std::vector<long long>> turns;  // turn -> time of phase 0..9 (-1: none)
         std::map<uint32_t, int> who;
@@ -57,7 +57,7 @@ int main(int argc, char **argv)
                 // a stamp 0 ("starts waiting") carries the turn the wave waits for; 9 carries the turn + W it goes to next
                 uint32_t key = id == 9 ? turn - W : turn;
                 auto &v = turns[key];
-                if (v.empty()) v.assign(11, -1);
+                if (v.empty()) v.assign(16, -1);
                 if (v[id] < 0) v[id] = t;
                 who[key] = w;
             }
@@ -74,6 +74,7 @@ int main(int argc, char **argv)
             if (v[7] >= 0) opwait += v[7] - v[6];
             if (v[8] >= 0 && v[7] >= 0) seg[8] += v[8] - v[7];
             if (v[9] >= 0 && v[8] >= 0) seg[9] += v[9] - v[8];
+            if (v[11] >= 0 && v[3] >= 0 && v[15] >= 0) { fine[0] += v[11] - v[3]; fine[1] += v[12] - v[11]; fine[2] += v[13] - v[12]; fine[3] += v[14] - v[13]; fine[4] += v[15] - v[14]; nfine++; }
             if (v[10] >= 0) idle += v[1] - v[10];
             if (v[9] >= 0) busy += v[9] - v[1];
             if (v[10] >= 0 && v[0] >= 0) headt += v[10] - v[0];
@@ -93,6 +94,7 @@ int main(int argc, char **argv)
     printf("    P-1, lookups checked              %8.1f\n", seg[2] / nturn);
     printf("    patch (first visit)               %8.1f\n", seg[3] / nturn);
     printf("    visits (walk, exit, commit)       %8.1f\n", seg[4] / nturn);
+    if (nfine) printf("      first visit: entry lane + quit checks %.1f, walk %.1f, exit state + masks %.1f, conflict test %.1f, commit %.1f (each with one stamp: see 'long match length' for a stamp alone)\n", fine[0] / nfine, fine[1] / nfine, fine[2] / nfine, fine[3] / nfine, fine[4] / nfine);
     printf("    long match length                 %8.1f\n", seg[5] / nturn);
     printf("    publish                           %8.1f\n", seg[6] / nturn);
     printf("    hand-off (published -> acquired)  %8.1f\n", handoff / nper);
