@@ -444,6 +444,12 @@ static constexpr uint32_t kTeamNotMine = 0xfffffffcu; // return value of the wav
 #ifndef SZ_TEAM_SPIN_CAP
 #define SZ_TEAM_SPIN_CAP (1u << 24)  // polls before a waiting wave gives the block up (seconds: only a lost wave gets there)
 #endif
+#ifndef SZ_TEAM_BASE_PRIO
+#define SZ_TEAM_BASE_PRIO 1  // issue priority of a team's waves off the token's path (the lone waves of a workgroup have 0)
+#endif
+#ifndef SZ_TEAM_POLL_SLEEP
+#define SZ_TEAM_POLL_SLEEP 3  // s_sleep units (64 clocks) between two polls of a token
+#endif
 #ifndef SZ_TEAM_PRIO
 #define SZ_TEAM_PRIO 2  // issue priority of the wave that holds the parse token
 #endif
@@ -509,7 +515,7 @@ __device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t tur
             lost = 1;
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SZ_TEAM_POLL_SLEEP);
     }
     asm volatile("" ::: "memory");  // nothing of what follows is read before the token
     return v;
@@ -1136,7 +1142,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         if (cont)
                             team_publish(team.ptok, team_pack_parse(myturn + 1, P2, chain2, sc2, pm1_done, next_emit));
                         if (SZ_TEAM_PRIO)
-                            __builtin_amdgcn_s_setprio(0);
+                            __builtin_amdgcn_s_setprio(SZ_TEAM_BASE_PRIO);
                         TRACE(6); MARK("T6");
                         // ---- element writer of this tile: where do its elements begin?
                         if (!own_op) {
@@ -2070,7 +2076,7 @@ __device__ __forceinline__ uint32_t block_length(const uint32_t *__restrict__ in
 // the single kernel whole.  Hence opt-in.
 __global__ __launch_bounds__(64) void reset_launch_state_kernel(uint32_t *__restrict__ select)
 {
-    if (threadIdx.x < 4)
+    if (threadIdx.x < 16)
         select[threadIdx.x] = 0;
 }
 
@@ -2081,22 +2087,70 @@ __device__ __forceinline__ bool prefers_dual(const uint32_t *__restrict__ select
     return (uint64_t)select[0] * 10 > select[1];  // repeats > 10 % of the sampled positions
 }
 
+// Cost class of one block, by one wave (see "longest blocks first" below): 0 cheap (no repeats among the shingles of
+// its first 1 KiB: the scan accelerates), 1 medium (repeats, but few distinct strings among 128 samples spread over
+// the block: it repeats itself at long range, long matches skip most of it; or a short block), 2 expensive.
+// `bitmap`: 384 zeroed words of LDS of this wave's own.
+__device__ __forceinline__ uint32_t block_cost_class(const uint8_t *__restrict__ in, uint32_t n, uint32_t lane, uint32_t *bitmap)
+{
+    const uint32_t n1 = n < 1024 ? n : 1024;
+    const uint32_t npos = n1 >= 4 ? n1 - 3 : 0;
+    uint32_t dups = 0;
+    for (uint32_t p = lane; p < npos; p += 64) {
+        const uint32_t h = (ld32(in + p) * kHashMul) >> 19;  // 13 bits
+        const uint32_t bit = 1u << (h & 31u);
+        dups += (atomicOr(&bitmap[h >> 5], bit) & bit) ? 1u : 0u;
+    }
+    uint32_t fresh = 0, nsamp = 0;
+    if (n >= 4096) {
+        // (a power-of-two stride for a full block: data that repeats with a period that divides a multiple of 512
+        // -- pages, records, a pattern tiled over the block -- shows few distinct samples)
+        const uint32_t stride = n >> 7;  // 128 samples over the block; the last one ends at 127 n / 128 + 8 <= n
+        nsamp = 128;
+        for (uint32_t k = lane; k < 128; k += 64) {
+            const uint64_t v = ld64(in + k * stride);
+            const uint32_t h = ((uint32_t)((v * 0x9e3779b97f4a7c15ull) >> 40)) & 4095u;
+            const uint32_t bit = 1u << (h & 31u);
+            fresh += (atomicOr(&bitmap[256 + (h >> 5)], bit) & bit) ? 0u : 1u;
+        }
+    }
+    dups = lane_get(wave_inclusive_sum(dups), 63);
+    fresh = lane_get(wave_inclusive_sum(fresh), 63);
+    uint32_t c = 0;
+    if ((uint64_t)dups * 10 > npos)
+        c = (nsamp && fresh * 2 < nsamp) ? 1u : (n >= 4096 ? 2u : 1u);
+    return c;
+}
+// The launch sample saw blocks of more than one cost class (select[7] = classes seen): ordering the queue pays
+__device__ __forceinline__ bool launch_is_mixed(const uint32_t *__restrict__ select)
+{
+    return __builtin_popcount(select[7] & 7u) >= 2;
+}
+
 __global__ __launch_bounds__(256) void sample_compressibility_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint32_t *__restrict__ select)
 {
     __shared__ uint32_t bitmap[2048];  // 65536 bits
+    __shared__ uint32_t class_bm[384];
     __shared__ uint32_t wg_dups;
     const uint32_t t = threadIdx.x;
     for (uint32_t i = t; i < 2048; i += 256)
         bitmap[i] = 0;
+    for (uint32_t i = t; i < 384; i += 256)
+        class_bm[i] = 0;
     if (t == 0)
         wg_dups = 0;
     __syncthreads();
     const uint32_t b = (uint32_t)(((uint64_t)blockIdx.x * n_blocks) / gridDim.x);
     uint32_t n = block_length(in_len, total_len, in_stride, b);
-    n = n > kMaxBlock ? 0 : (n < 1024 ? n : 1024);  // text repeats >= 23 % of its shingles within 1 KiB
     const uint8_t *in = src + (uint64_t)b * in_stride;
+    if (t < 64) {  // the cost classes the launch holds (does ordering its queue pay?)
+        const uint32_t c = block_cost_class(in, n > kMaxBlock ? 0 : n, t, class_bm);
+        if (t == 0)
+            atomicOr(&select[7], 1u << c);
+    }
+    n = n > kMaxBlock ? 0 : (n < 1024 ? n : 1024);  // text repeats >= 23 % of its shingles within 1 KiB
     const uint32_t npos = n >= 4 ? n - 3 : 0;
     uint32_t dups = 0;
     for (uint32_t p = t; p < npos; p += 256) {
@@ -2112,6 +2166,65 @@ __global__ __launch_bounds__(256) void sample_compressibility_kernel(
     }
 }
 
+
+// ---- longest blocks first (round 3): the persistent kernels hand out blocks from one queue, and a launch that
+// mixes kinds of data ends with a tail in which the last expensive blocks run alone (a 64 KiB block of text takes
+// ~100 x as long as an incompressible one, ~10 x as long as one that is a few long matches).  Blocks cannot be
+// split, so the lever is their order: a cheap estimate per block, three cost classes, the expensive class first.
+//   * repeats among the 4-byte shingles of the block's first 1 KiB (the launch sample's measure, per block):
+//     few -> the scan accelerates, strided probes, cheap (class 0);
+//   * otherwise, distinct 8-byte strings among 128 samples spread evenly over the block: few -> the block
+//     repeats itself at long range (long matches skip most of it), medium (class 1); many -> dense parse
+//     of the whole block, expensive (class 2).
+// The estimate only orders the queue: every block is compressed by the same code whatever its class.
+// select[4..6] = blocks per class, select[8..10] = cursors of the placement, select[3] = n_blocks for the
+// kernel that reads the queue.  `cls` = one byte per block (the upper half of the queue buffer).
+__global__ __launch_bounds__(256) void classify_blocks_kernel(
+    const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len, uint64_t total_len,
+    uint32_t n_blocks, uint8_t *__restrict__ cls, uint32_t *__restrict__ select, uint32_t auto_mode)
+{
+    __shared__ uint32_t bitmaps[4][384];
+    if (auto_mode && !(prefers_dual(select) && launch_is_mixed(select)))
+        return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * 4u + wave;  // one wave per block
+    for (uint32_t i = lane; i < 384; i += 64)
+        bitmaps[wave][i] = 0;
+    __syncthreads();
+    if (b >= n_blocks)
+        return;
+    const uint32_t n = block_length(in_len, total_len, in_stride, b);
+    const uint32_t c = block_cost_class(src + (uint64_t)b * in_stride, n > kMaxBlock ? 0 : n, lane, bitmaps[wave]);
+    if (lane == 0) {
+        cls[b] = (uint8_t)c;
+        atomicAdd(&select[4 + c], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void place_blocks_kernel(const uint8_t *__restrict__ cls, uint32_t n_blocks,
+                                                          uint32_t *__restrict__ queue, uint32_t *__restrict__ select,
+                                                          uint32_t auto_mode)
+{
+    if (auto_mode && !(prefers_dual(select) && launch_is_mixed(select)))
+        return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t c = i < n_blocks ? cls[i] : 3u;
+    const uint32_t n2 = select[6], n1 = select[5];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {  // one atomic per wave and class
+        const uint64_t m = ballot64(c == k);
+        if (m == 0)
+            continue;
+        uint32_t base = 0;
+        if (lane == 0)
+            base = atomicAdd(&select[8 + k], (uint32_t)__builtin_popcountll(m));
+        base = uni(base) + (k == 2 ? 0u : k == 1 ? n2 : n2 + n1);  // expensive first, cheap last
+        if (c == k)
+            queue[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1))] = i;
+    }
+    if (i == 0)
+        select[3] = n_blocks;
+}
 
 // Between the two kernels (SZ_KERNEL=route): the blocks the single kernel marked, as a compact queue for the
 // multi-wave kernel's waves.  One ballot and one atomic add per wave of 64 blocks (the order of the
@@ -2187,10 +2300,12 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
     __shared__ uint32_t dup_bm[(kGroupWaves - 1) * 512];  // one 16384-bit bitmap per global-table wave
-    if (auto_mode && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
+    if ((auto_mode & 1u) && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
         return;
     // route mode (queue != nullptr): the blocks of this launch's queue, filled behind the single kernel
     // (an all-incompressible launch leaves it empty: every workgroup is gone before it does anything)
+    if ((auto_mode & 2u) && (auto_mode & 1u) && !launch_is_mixed(select))
+        queue = nullptr;  // an order queue, and the sample found one kind of block only: it was not filled
     const uint32_t n_work = queue ? uni(select[3]) : n_blocks;
     if (blockIdx.x * kGroupWaves >= n_work)
         return;
@@ -2275,8 +2390,10 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
     __shared__ __attribute__((aligned(16))) uint8_t dup_scr[kTeamWaves * 256];
     __shared__ uint32_t lone_bm[(kLoneWaves > 0 ? kLoneWaves : 1) * 512];  // one 16384-bit bitmap per global-table wave
     __shared__ uint32_t next_block, team_bar;
-    if (auto_mode && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
+    if ((auto_mode & 1u) && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
         return;
+    if ((auto_mode & 2u) && (auto_mode & 1u) && !launch_is_mixed(select))
+        queue = nullptr;  // an order queue, and the sample found one kind of block only: it was not filled
     const uint32_t n_work = queue ? uni(select[3]) : n_blocks;
     if (blockIdx.x * (1u + kLoneWaves) >= n_work)
         return;
@@ -2321,7 +2438,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
     }
     const HashTab<true> tab{lds_tab, nullptr, nullptr};
     WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr, dup_scr + wave * 256u, &team_bar};
-    __builtin_amdgcn_s_setprio(1);  // (a team's waves go before the lone ones; the token's holder before both)
+    __builtin_amdgcn_s_setprio(SZ_TEAM_BASE_PRIO);  // (a team's waves go before the lone ones; the token's holder before both)
     for (;;) {
         if (wave == 0) {
             const uint32_t b0 = next_index();
@@ -2413,6 +2530,16 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
     if (route)
         hipLaunchKernelGGL(compact_routed_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, d_out_len, n_blocks,
                            dual->queue, dual->select);
+    // longest blocks first: the queue of the persistent kernel in cost order (not with route, which has a queue of its own)
+    const bool ordered = dual_ok && !route && dual->queue && n_blocks >= 256 && 2ull * n_blocks <= dual->queue_cap;
+    if (ordered) {
+        uint8_t *cls = reinterpret_cast<uint8_t *>(dual->queue + dual->queue_cap / 2);
+        hipLaunchKernelGGL(classify_blocks_kernel, dim3((n_blocks + 3) / 4), dim3(256), 0, stream, src, in_stride, d_in_len, total_len,
+                           n_blocks, cls, dual->select, sampled ? 1u : 0u);
+        hipLaunchKernelGGL(place_blocks_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, cls, n_blocks,
+                           dual->queue, dual->select, sampled ? 1u : 0u);
+    }
+    const uint32_t *work_queue = (route || ordered) ? dual->queue : (const uint32_t *)nullptr;
     if (dual_ok) {
         // enough blocks to keep kGroupWaves waves per SIMD busy on every CU: persistent grid
         if (dual->kernel == kKernelTeam) {
@@ -2421,14 +2548,14 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
             static_assert(kLoneWaves <= (int)kDualTablesPerGroup, "the workspace has kDualTablesPerGroup tables per workgroup");
             hipLaunchKernelGGL(compress_blocks_team_kernel, dim3(tgrid), dim3(64 * kHybridWaves), 0, stream, src, in_stride,
                                d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->tables, dual->select,
-                               route ? dual->queue : (const uint32_t *)nullptr, sampled ? 1u : 0u);
+                               work_queue, (sampled ? 1u : 0u) | (ordered ? 2u : 0u));
             return hipGetLastError();
         }
         uint32_t grid = (n_blocks + kGroupWaves - 1) / kGroupWaves;
         grid = grid < dual->n_slots ? grid : dual->n_slots;
         hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(64 * kGroupWaves), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->tables,
-                           dual->select, route ? dual->queue : (const uint32_t *)nullptr, sampled ? 1u : 0u);
+                           dual->select, work_queue, (sampled ? 1u : 0u) | (ordered ? 2u : 0u));
     }
     return hipGetLastError();
 }
