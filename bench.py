@@ -225,6 +225,29 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
             "decompress": dec, "layout": layout}
 
 
+def copy_roof(n_bytes, device, reps=10):
+    """A plain device-to-device copy of as many bytes as the headline workload reads (torch's copy kernel, the
+    same process, the same box, HIP events on the stream it runs on): what this part moves when a kernel
+    does nothing but copy.  Returns in+out GB/s (best and mean of `reps` after two warm-ups)."""
+    import torch
+    a = torch.empty(n_bytes, dtype=torch.uint8, device=device)
+    a.random_(0, 255)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    del a, b
+    return {"best": 2.0 * n_bytes / (min(ms) * 1e-3) / 1e9, "mean": 2.0 * n_bytes / (sum(ms) / len(ms) * 1e-3) / 1e9}
+
+
 # -------------------------------------------------------------------------------------- CPU baseline
 
 def effective_cores():
@@ -363,9 +386,10 @@ def rank_main(args):
         for kind, nb in (("text", 16384), ("c5", 16384), ("mix", 16386)):
             if kind == args.workload:
                 continue
-            r = run_workload(P, kind, rank * nb, nb, 3, 1, device, dist_on, decompress=True)
+            xsteps = 10
+            r = run_workload(P, kind, rank * nb, nb, xsteps, 2, device, dist_on, decompress=True)
             k_ms = float(np.mean(r["kernel_ms"]))
-            extras[kind] = {"input_GBps": round(r["in_bytes"] * world * 3 / r["elapsed_s"] / 1e9, 2),
+            extras[kind] = {"input_GBps": round(r["in_bytes"] * world * xsteps / r["elapsed_s"] / 1e9, 2), "steps": xsteps,
                             "kernel_ms": round(k_ms, 3), "blocks_per_gpu": nb,
                             "compression_ratio": round(r["in_bytes"] / r["out_bytes"], 4),
                             "hbm_frac_in_plus_out": round((r["in_bytes"] + r["out_bytes"]) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -389,10 +413,13 @@ def rank_main(args):
         algo_bytes = main_res["in_bytes"] + main_res["out_bytes"] + 4 * B  # per launch (this rank)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/pmc_summary.py)
+        pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_%s_%d.json" % (args.workload, B))
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                traffic = json.load(f).get("hbm_traffic_bytes_per_launch")
+                pmc = json.load(f)
+            traffic = pmc.get("hbm_traffic_bytes_per_launch")
+        roof = copy_roof(main_res["in_bytes"], device) if world == 1 else None
         line = {
             "metric": "snappy_compress_input_GBps_64KiB_blocks",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -402,7 +429,7 @@ def rank_main(args):
                                     "c5": "C5 4 KiB text pattern x16", "mix": "C4 mix c3/text/c5"}[args.workload]
                        + ", %d x 64 KiB blocks per GPU (%.2f GiB/GPU)" % (B, B * BLOCK / 2**30),
                        "blocks_per_gpu": B, "block_bytes": BLOCK,
-                       "kernel": os.environ.get("SZ_KERNEL", "auto (sampled: single for incompressible, dual otherwise)"),
+                       "kernel": os.environ.get("SZ_KERNEL", "auto (sampled: single kernel for incompressible launches, team kernel otherwise)"),
                        "sharding": "contiguous block ranges, no data-path collective; all_gather of uint32 lengths over RCCL",
                        "device": props.name},
             "compressed_size_ratio_vs_ref": 1.0 if bad_all == 0 else None,
@@ -413,6 +440,13 @@ def rank_main(args):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": int(traffic) if traffic else None,
+                         "traffic_source": "profiles/%s (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)" % os.path.basename(pmc_path) if traffic else None,
+                         "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"),
+                         "resident_waves_per_simd": pmc.get("resident_waves_per_simd"),
+                         "copy_roof_GBps": round(roof["best"], 1) if roof else None,
+                         "copy_roof_mean_GBps": round(roof["mean"], 1) if roof else None,
+                         "frac_of_copy_roof": round(achieved / roof["best"], 4) if roof else None,
+                         "copy_roof_what": "torch device-to-device copy of the same %d input bytes, in+out bytes / HIP-event time, same process" % main_res["in_bytes"] if roof else None,
                          "kernel": "szk::compress_blocks_kernel", "kernel_ms_avg": round(k_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "peak_source": "MI355X HBM3E spec (MI355X_MICROARCH.md); device reports %s, %d CUs"

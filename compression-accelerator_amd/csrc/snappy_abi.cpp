@@ -32,9 +32,21 @@ namespace {
 struct DualSlot {
     szk::DualScratch sc{nullptr, nullptr, nullptr, 0, 0, 0, szk::kDualAuto, szk::kKernelTeam};
     std::mutex launch_mu;
+    DualSlot() = default;
+    DualSlot(const DualSlot &) = delete;
+    DualSlot &operator=(const DualSlot &) = delete;
+    ~DualSlot()
+    {
+        if (sc.tables)
+            (void)hipFree(sc.tables);
+        if (sc.select)
+            (void)hipFree(sc.select);
+        if (sc.queue)
+            (void)hipFree(sc.queue);
+    }
 };
 std::mutex g_dual_mutex;
-std::map<std::pair<int, hipStream_t>, std::unique_ptr<DualSlot>> g_dual;
+std::map<std::pair<int, hipStream_t>, std::shared_ptr<DualSlot>> g_dual;
 
 int kernel_mode()
 {
@@ -51,10 +63,16 @@ int kernel_mode()
 // The workspace slot of (current device, stream) for a launch of n_blocks, or nullptr when the
 // single kernel is to run (mode, too few blocks, no memory, stream being captured before a first use).
 // `view` receives the launch parameters for this call.
-DualSlot *dual_slot_for(hipStream_t stream, uint32_t n_blocks, szk::DualScratch *view)
+// (The slot is returned as a shared_ptr: a concurrent sz_release_stream_resources / Workspace::release of the
+// same stream removes it from the map but cannot destroy it -- nor free its buffers, see drop_dual_scratch --
+// while a launcher still holds it.)  Launches that the small-block kernel takes never use the workspace.
+std::shared_ptr<DualSlot> dual_slot_for(hipStream_t stream, uint32_t n_blocks, size_t in_stride, const uint32_t *d_in_len,
+                                        szk::DualScratch *view)
 {
     const int mode = kernel_mode();
     if (mode == 1)
+        return nullptr;
+    if (!d_in_len && in_stride <= 8192)  // fixed small blocks: compress_small_blocks_kernel (launch_any), no workspace
         return nullptr;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess)
@@ -74,7 +92,7 @@ DualSlot *dual_slot_for(hipStream_t stream, uint32_t n_blocks, szk::DualScratch 
             (void)hipGetLastError();
             return nullptr;  // no allocation while a graph is being captured: single kernel this time
         }
-        std::unique_ptr<DualSlot> slot(new DualSlot);
+        std::shared_ptr<DualSlot> slot(new DualSlot);
         slot->sc.n_slots = n_slots;
         void *t = nullptr, *g = nullptr, *q = nullptr;
         const size_t gbytes = 64;  // launch state
@@ -96,7 +114,7 @@ DualSlot *dual_slot_for(hipStream_t stream, uint32_t n_blocks, szk::DualScratch 
         }
         it = g_dual.emplace(key, std::move(slot)).first;
     }
-    DualSlot *s = it->second.get();
+    std::shared_ptr<DualSlot> s = it->second;
     *view = s->sc;
     view->mode = (mode == 2 || mode == 4) ? szk::kDualAlways : mode == 3 ? szk::kDualRoute : szk::kDualAuto;
     // compressible launches: the team kernel (a two-wave team on the LDS table + two global-table waves per
@@ -111,7 +129,7 @@ DualSlot *dual_slot_for(hipStream_t stream, uint32_t n_blocks, szk::DualScratch 
 // Frees the multi-wave workspace that belongs to a stream which is about to be destroyed.
 void drop_dual_scratch(int dev, hipStream_t stream)
 {
-    std::unique_ptr<DualSlot> slot;
+    std::shared_ptr<DualSlot> slot;
     {
         std::lock_guard<std::mutex> lock(g_dual_mutex);
         auto it = g_dual.find(std::make_pair(dev, stream));
@@ -120,13 +138,9 @@ void drop_dual_scratch(int dev, hipStream_t stream)
         slot = std::move(it->second);
         g_dual.erase(it);
     }
+    // The buffers go when the last holder lets go of the slot (a launcher that looked it up a moment ago may be
+    // about to lock launch_mu and enqueue on them): the destructor of the slot frees them.
     std::lock_guard<std::mutex> launch(slot->launch_mu);  // (no launch sequence is half enqueued)
-    if (slot->sc.tables)
-        (void)hipFree(slot->sc.tables);
-    if (slot->sc.select)
-        (void)hipFree(slot->sc.select);
-    if (slot->sc.queue)
-        (void)hipFree(slot->sc.queue);
 }
 
 thread_local int tl_hip_error = 0;
@@ -280,7 +294,7 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
         flags |= (uint32_t)strtoul(dbg, nullptr, 0) & 0xff00u;
 #endif
     szk::DualScratch view;
-    DualSlot *slot = dual_slot_for(static_cast<hipStream_t>(stream), n_blocks, &view);
+    std::shared_ptr<DualSlot> slot = dual_slot_for(static_cast<hipStream_t>(stream), n_blocks, in_stride, d_in_len, &view);
     std::unique_lock<std::mutex> seq;  // one launch sequence at a time per workspace
     if (slot)
         seq = std::unique_lock<std::mutex>(slot->launch_mu);
@@ -301,7 +315,7 @@ int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t sl
         return SZ_ENOSPC;
     const uint32_t n_blocks = (uint32_t)((n + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
     szk::DualScratch view;
-    DualSlot *slot = dual_slot_for(static_cast<hipStream_t>(stream), n_blocks, &view);
+    std::shared_ptr<DualSlot> slot = dual_slot_for(static_cast<hipStream_t>(stream), n_blocks, SZ_BLOCK_SIZE, nullptr, &view);
     std::unique_lock<std::mutex> seq;  // one launch sequence at a time per workspace
     if (slot)
         seq = std::unique_lock<std::mutex>(slot->launch_mu);

@@ -389,6 +389,7 @@ struct tjob {
     pthread_barrier_t *bar;
     double *seconds;
     int leader;
+    int *gate; /* 0: wait, 1: every thread exists, run; -1: a thread could not be created, leave */
 };
 
 /* one pass over this thread's blocks with an external compressor (same buffers, same partition) */
@@ -407,6 +408,12 @@ static void ext_pass(struct tjob *t)
 static void *tjob_main(void *arg)
 {
     struct tjob *t = (struct tjob *)arg;
+    /* (the barrier is sized for all threads: nobody enters it before all of them exist) */
+    int g;
+    while ((g = __atomic_load_n(t->gate, __ATOMIC_ACQUIRE)) == 0)
+        sched_yield();
+    if (g < 0)
+        return NULL;
     if (t->cpu >= 0) {
         cpu_set_t set;
         CPU_ZERO(&set);
@@ -480,6 +487,7 @@ static int time_blocks(ext_compress_fn ext, const uint8_t *src, size_t in_stride
         return -2;
     }
     *seconds = 0.0;
+    int gate = 0, created = 0, failed = 0;
     for (int t = 0; t < n_threads; t++) {
         jobs[t].j = (struct job){src, in_stride, NULL, dst, dst_stride, out_len, per_block_varint,
                                  (uint32_t)((uint64_t)n_blocks * t / n_threads),
@@ -490,15 +498,20 @@ static int time_blocks(ext_compress_fn ext, const uint8_t *src, size_t in_stride
         jobs[t].bar = &bar;
         jobs[t].seconds = seconds;
         jobs[t].leader = t == 0;
-        if (t > 0)
-            pthread_create(&tids[t], NULL, tjob_main, &jobs[t]);
+        jobs[t].gate = &gate;
     }
-    /* the leader runs on a thread of its own too, so that pinning never touches the caller */
-    pthread_create(&tids[0], NULL, tjob_main, &jobs[0]);
-    for (int t = 0; t < n_threads; t++)
+    /* (the leader runs on a thread of its own too, so that pinning never touches the caller) */
+    for (int t = 0; t < n_threads && !failed; t++) {
+        if (pthread_create(&tids[t], NULL, tjob_main, &jobs[t]) == 0)
+            created++;
+        else
+            failed = 1; /* RLIMIT_NPROC, the cgroup's pids limit ...: no thread may wait at the barrier */
+    }
+    __atomic_store_n(&gate, failed ? -1 : 1, __ATOMIC_RELEASE);
+    for (int t = 0; t < created; t++)
         pthread_join(tids[t], NULL);
     pthread_barrier_destroy(&bar);
     free(jobs);
     free(tids);
-    return 0;
+    return failed ? -3 : 0;
 }

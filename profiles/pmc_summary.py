@@ -40,6 +40,12 @@ def main():
         res["hbm_traffic_bytes_per_launch"] = res["hbm_read_bytes_per_launch"] + res["hbm_write_bytes_per_launch"]
     if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
         res["lds_bank_conflict_frac_of_lds_active"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
+        res["lds_bank_conflict_frac"] = res["lds_bank_conflict_frac_of_lds_active"]
+    if "SQ_WAVE_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
+        # waves resident per SIMD, averaged over the kernel: wave-residency (quad-cycles, summed over waves) over
+        # the kernel's duration (GRBM_GUI_ACTIVE is summed over the 8 XCDs, in clocks) x 1 024 SIMDs
+        res["resident_waves_per_simd"] = c["SQ_WAVE_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0)
     if "SQ_WAVE_CYCLES" in c and c.get("SQ_WAVES"):
         res["wave_cycles_per_wave_(quad_cycles)"] = c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"]
         res["wait_frac"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]

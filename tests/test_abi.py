@@ -129,10 +129,13 @@ def test_no_reloaded_spill_feeds_a_memory_instruction_scalar_base(tmp_path):
             if not m:
                 continue
             lo = "s%s," % m.group(2)
-            for j in range(max(0, i - 12), i):
-                if "v_readlane_b32 " + lo in lines[j]:
-                    offenders.append("%s: %s  <-  %s" % (name, l.strip(), lines[j].strip()))
-                    break
+            pair = "s[%s:%s]," % (m.group(2), m.group(3))
+            for j in range(i - 1, max(-1, i - 13), -1):  # the CLOSEST writer of the base's low half decides
+                w = lines[j].split()
+                if len(w) >= 2 and w[1] in (lo, pair):
+                    if w[0] == "v_readlane_b32":
+                        offenders.append("%s: %s  <-  %s" % (name, l.strip(), lines[j].strip()))
+                    break  # (written by anything else in between: not a reloaded spill any more)
     assert not offenders, "\n".join(offenders)
 
 
