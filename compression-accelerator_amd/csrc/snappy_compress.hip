@@ -2187,17 +2187,19 @@ __global__ __launch_bounds__(256) void classify_blocks_kernel(
     if (auto_mode && !(prefers_dual(select) && launch_is_mixed(select)))
         return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x * 4u + wave;  // one wave per block
-    for (uint32_t i = lane; i < 384; i += 64)
-        bitmaps[wave][i] = 0;
-    __syncthreads();
-    if (b >= n_blocks)
-        return;
-    const uint32_t n = block_length(in_len, total_len, in_stride, b);
-    const uint32_t c = block_cost_class(src + (uint64_t)b * in_stride, n > kMaxBlock ? 0 : n, lane, bitmaps[wave]);
-    if (lane == 0) {
-        cls[b] = (uint8_t)c;
-        atomicAdd(&select[4 + c], 1u);
+    // one wave per block; a bounded grid that strides over the launch (a launch that does not order its queue pays
+    // for the workgroups that leave at once: a few microseconds, which a 0.8 ms incompressible launch notices)
+    for (uint32_t b = blockIdx.x * 4u + wave; b < n_blocks; b += gridDim.x * 4u) {
+        for (uint32_t i = lane; i < 384; i += 64)
+            bitmaps[wave][i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n = block_length(in_len, total_len, in_stride, b);
+        const uint32_t c = block_cost_class(src + (uint64_t)b * in_stride, n > kMaxBlock ? 0 : n, lane, bitmaps[wave]);
+        if (lane == 0) {
+            cls[b] = (uint8_t)c;
+            atomicAdd(&select[4 + c], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -2207,22 +2209,25 @@ __global__ __launch_bounds__(256) void place_blocks_kernel(const uint8_t *__rest
 {
     if (auto_mode && !(prefers_dual(select) && launch_is_mixed(select)))
         return;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
-    const uint32_t c = i < n_blocks ? cls[i] : 3u;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n2 = select[6], n1 = select[5];
+    for (uint32_t i0 = blockIdx.x * 256u; i0 < n_blocks; i0 += gridDim.x * 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t c = i < n_blocks ? cls[i] : 3u;
 #pragma unroll
-    for (uint32_t k = 0; k < 3; k++) {  // one atomic per wave and class
-        const uint64_t m = ballot64(c == k);
-        if (m == 0)
-            continue;
-        uint32_t base = 0;
-        if (lane == 0)
-            base = atomicAdd(&select[8 + k], (uint32_t)__builtin_popcountll(m));
-        base = uni(base) + (k == 2 ? 0u : k == 1 ? n2 : n2 + n1);  // expensive first, cheap last
-        if (c == k)
-            queue[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1))] = i;
+        for (uint32_t k = 0; k < 3; k++) {  // one atomic per wave and class
+            const uint64_t m = ballot64(c == k);
+            if (m == 0)
+                continue;
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&select[8 + k], (uint32_t)__builtin_popcountll(m));
+            base = uni(base) + (k == 2 ? 0u : k == 1 ? n2 : n2 + n1);  // expensive first, cheap last
+            if (c == k)
+                queue[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1))] = i;
+        }
     }
-    if (i == 0)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
         select[3] = n_blocks;
 }
 
@@ -2534,9 +2539,11 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
     const bool ordered = dual_ok && !route && dual->queue && n_blocks >= 256 && 2ull * n_blocks <= dual->queue_cap;
     if (ordered) {
         uint8_t *cls = reinterpret_cast<uint8_t *>(dual->queue + dual->queue_cap / 2);
-        hipLaunchKernelGGL(classify_blocks_kernel, dim3((n_blocks + 3) / 4), dim3(256), 0, stream, src, in_stride, d_in_len, total_len,
+        const uint32_t cgrid = (n_blocks + 3) / 4 < 2048u ? (n_blocks + 3) / 4 : 2048u;
+        const uint32_t pgrid = (n_blocks + 255) / 256 < 256u ? (n_blocks + 255) / 256 : 256u;
+        hipLaunchKernelGGL(classify_blocks_kernel, dim3(cgrid), dim3(256), 0, stream, src, in_stride, d_in_len, total_len,
                            n_blocks, cls, dual->select, sampled ? 1u : 0u);
-        hipLaunchKernelGGL(place_blocks_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, cls, n_blocks,
+        hipLaunchKernelGGL(place_blocks_kernel, dim3(pgrid), dim3(256), 0, stream, cls, n_blocks,
                            dual->queue, dual->select, sampled ? 1u : 0u);
     }
     const uint32_t *work_queue = (route || ordered) ? dual->queue : (const uint32_t *)nullptr;
