@@ -126,20 +126,46 @@ __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *
     for (uint32_t i = lane; i < n_chk; i += 64)
         my_chk[i] = make_uint2(kBad, 0);
     uint32_t pos = seg_base + lane, out = 0;  // hypothetical parse number `lane`
-    uint32_t next_mark = 0;                   // (lane 0) the next KiB mark without a checkpoint
+    uint32_t next_mark = 0;                   // the next KiB mark without a checkpoint
+    uint32_t ref = 0;                         // the hypothesis whose checkpoints are being recorded
     for (;;) {
         const bool active = pos < seg_end;  // (kBad and exits are >= seg_end)
         if (__ballot(active) == 0)
             break;
-        if (lane == 0 && active) {
-            const uint32_t mk = (pos - seg_base) >> kChkShift;
-            if (mk >= next_mark) {  // first element start at or past mark mk (and any mark skipped before it)
-                for (uint32_t j = next_mark; j <= mk; j++)
-                    my_chk[j] = make_uint2(pos, out);
+        const uint32_t wb = uni(wave_min(active ? pos : kBad));
+        {
+            // Checkpoints of ONE hypothesis, the reference: at every KiB mark the first of its element starts that
+            // this loop sees at or past the mark, the bytes it has produced by then, and its number (bits 26..31:
+            // a segment produces < 64 MiB).  Hypothesis 0 is the reference while it lives; a hypothesis that runs
+            // away (a stretch of payload read as a literal of megabytes leaves the segment at once: ~1 % of text
+            // segments for any given one) is replaced by the lowest one still inside the segment.  Parses fall
+            // into step within a few elements, so the reference is the true parse from its first or second
+            // checkpoint on; a reader uses the checkpoints of one number only.
+            const uint64_t live = __ballot(active);
+            if (!((live >> ref) & 1))
+                ref = (uint32_t)__builtin_ctzll(live);  // (live != 0 here)
+            uint32_t rpos = lane_get(pos, ref);
+            uint32_t mk = (rpos - seg_base) >> kChkShift;
+            if (mk >= next_mark && rpos >= wb + 64) {
+                // the reference is about to leave a checkpoint far ahead of the hindmost parse: one of the two is
+                // reading payload as elements (a fake literal of kilobytes that stays inside the segment, or the
+                // parses that started inside a real one).  The one more hypotheses have joined is the better
+                // reference either way: where it is wrong, the true parse is one long element and needs no checkpoint.
+                const uint64_t hind = __ballot(active && pos == wb);
+                if (__builtin_popcountll(hind) > __builtin_popcountll(__ballot(active && pos == rpos))) {
+                    ref = (uint32_t)__builtin_ctzll(hind);
+                    rpos = wb;
+                    mk = (rpos - seg_base) >> kChkShift;
+                }
+            }
+            if (mk >= next_mark) {
+                const uint32_t rout = lane_get(out, ref);
+                if (lane == 0)
+                    for (uint32_t j = next_mark; j <= mk; j++)
+                        my_chk[j] = make_uint2(rpos, (rout & 0x3ffffffu) | (ref << 26));
                 next_mark = mk + 1;
             }
         }
-        const uint32_t wb = uni(wave_min(active ? pos : kBad));
         uint32_t E, O;
         window_map(in, wb, seg_end, n, lane, E, O);
         const uint32_t rel = pos - wb;
@@ -256,10 +282,11 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
                     // may have jumped over is the same element or none of its own)
                     const uint2 c = chk[(size_t)s * n_chk + mark];
                     if (uni(c.x) == p) {
-                        const uint2 m = maps[(size_t)s * 64];  // hypothesis 0: (exit, bytes produced)
+                        // (the checkpoint's hypothesis: its exit and the bytes it has produced by then and by here)
+                        const uint2 m = maps[(size_t)s * 64 + (uni(c.y) >> 26)];
                         if (uni(m.x) == kBad)
                             return false;
-                        out += uni(m.y) - uni(c.y);
+                        out += uni(m.y) - (uni(c.y) & 0x3ffffffu);
                         p = uni(m.x);
                         merged = true;
                         break;
@@ -359,9 +386,16 @@ __global__ __launch_bounds__(64) void stream_chunk_entries_kernel(uint32_t n, ui
 // ---- 3. fragment boundaries inside each segment
 // off[m] := compressed offset of the element that starts at output position m * 64 KiB (0 < m < number
 // of fragments); flag |= 2 if an element straddles such a position, |= 1 on a malformed element.
+// A segment is NOT walked from end to end (round 2 did: 1.9 ms of a 1 GiB text stream's 8.0): the true parse is
+// followed from its entry only until it stands on a checkpoint of the segment's hypothesis 0 (pass 1 left one per
+// KiB; parses fall into step within a few elements) -- from there on the checkpoints ARE the true parse, shifted
+// by a constant number of output bytes, so every 64 KiB output boundary inside the segment is looked up among
+// them and only the KiB in front of it is walked.  (Elements on the true parse are well-formed: passes 1-2 have
+// followed it to the end of the stream, result[0].)
 __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t ulen,
                                                                uint32_t n_seg, uint32_t seg_shift,
                                                                const uint2 *__restrict__ entries,
+                                                               const uint2 *__restrict__ maps, const uint2 *__restrict__ chk,
                                                                unsigned long long *__restrict__ off,
                                                                uint32_t *__restrict__ flag)
 {
@@ -373,9 +407,24 @@ __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__
     uint32_t p = uni(en.x), out = uni(en.y);
     if (p == kBad)
         return;
+#ifdef SZ_STREAM_DEBUG
+    uint32_t dbg_windows = 0;
+    unsigned long long dbg_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_t0) :: "memory");
+#endif
     const uint32_t seg_base = s * kSeg;
     const uint32_t seg_end = seg_base + kSeg < n ? seg_base + kSeg : n;
-    while (p < seg_end) {
+    const uint32_t n_chk = kSeg >> kChkShift;
+    const uint2 *my_chk = chk + (size_t)s * n_chk;
+    uint32_t delta = 0, jm = kBad;  // true output position of checkpoint j = (chk[j].y & 0x3ffffff) + delta, for j >= jm
+    uint32_t rid = 0;               // ... of the hypothesis the parse has met (chk[j].y >> 26 == rid)
+    uint32_t mark = 0;              // the next KiB mark ahead of the walk
+    // one window of the walk: the elements that start in [p, p + 62] and inside the segment; records the ones that
+    // start on a boundary; false: a flag was raised (the caller decodes serially)
+    auto window = [&]() -> bool {
+#ifdef SZ_STREAM_DEBUG
+        dbg_windows++;
+#endif
         const uint32_t q = p + lane;
         Elem e;
         e.size = 0;
@@ -401,7 +450,7 @@ __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__
         if (__ballot(mine && !e.ok)) {
             if (lane == 0)
                 atomicOr(flag, 1u);
-            return;
+            return false;
         }
         const uint64_t Mm = __ballot(mine);  // a prefix of the chain (positions increase along it)
         const uint32_t e_last = 63u - (uint32_t)__builtin_clzll(Mm);  // lane 0 is always mine: Mm != 0
@@ -413,11 +462,78 @@ __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__
         if (__ballot(mine && (start >> 16) != ((start + olen - 1u) >> 16))) {
             if (lane == 0)
                 atomicOr(flag, 2u);
-            return;
+            return false;
+        }
+        // a KiB mark inside this window: is this parse's first element at or past it hypothesis 0's (the
+        // checkpoint of that mark)?  Then the parse stands THERE: the rest of the segment is looked up.
+        // (a checkpoint is AN element start of hypothesis 0 shortly behind its mark -- the first one pass 1 looked
+        // at, not necessarily the first one there is --: the parses have met if it is an element start of this
+        // parse too)
+        while (jm == kBad && mark < n_chk) {
+            const uint32_t cxm = uni(my_chk[mark].x);
+            const uint32_t wend = p + e_last + lane_get(e.size, e_last);  // where this window's chain ends
+            if (cxm == kBad || cxm >= wend)
+                break;  // no checkpoint for this mark (hypothesis 0 has ended), or it lies ahead of this window
+            if (cxm >= p && cxm - p < 64 && ((Mm >> (cxm - p)) & 1)) {
+                const uint32_t cym = uni(my_chk[mark].y);
+                jm = mark;
+                rid = cym >> 26;
+                delta = lane_get(start, cxm - p) - (cym & 0x3ffffffu);
+            } else {
+                mark++;  // behind this parse, or not one of its element starts: try the next mark's
+            }
         }
         out += lane_get(incl, 63);
         p += e_last + lane_get(e.size, e_last);
+        return true;
+    };
+    // ---- from the entry until the parse stands on a checkpoint of hypothesis 0 (or leaves the segment)
+    {
+        const uint32_t j0 = (p - seg_base) >> kChkShift;
+        if (uni(my_chk[j0].x) == p) {  // (an entry on a checkpoint, e.g. at the segment's first byte)
+            const uint32_t cy0 = uni(my_chk[j0].y);
+            jm = j0;
+            rid = cy0 >> 26;
+            delta = out - (cy0 & 0x3ffffffu);
+        }
     }
+    mark = ((p - seg_base) >> kChkShift) + 1;  // the next KiB mark ahead
+    while (jm == kBad && p < seg_end) {
+        if (!window())
+            return;
+    }
+    if (jm == kBad)
+        return;  // the whole segment was walked
+    // ---- the boundaries behind the meeting point: look each one up among the checkpoints, walk the KiB before it
+    const uint2 m0 = maps[(size_t)s * 64 + rid];  // that hypothesis: (exit, bytes produced) -- bytes at the exit = m0.y + delta
+    const uint32_t out_exit = uni(m0.y) + delta;
+    const uint32_t cyr = lane < n_chk ? my_chk[lane].y : 0u;
+    const uint32_t cx = (lane < n_chk && (cyr >> 26) == rid) ? my_chk[lane].x : kBad;  // (n_chk <= 64; one hypothesis' only)
+    const uint32_t cy = (cyr & 0x3ffffffu) + delta;
+    for (uint32_t B = (out + 0xffffu) & ~0xffffu; B < out_exit && B < ulen; B += 0x10000u) {
+        if (B == 0)
+            continue;
+        // the last checkpoint at or behind the meeting point whose element starts at or before B
+        const uint64_t okm = ballot64(lane >= jm && cx != kBad && cy <= B);
+        if (okm == 0)
+            break;  // (cannot happen: checkpoint jm qualifies)
+        const uint32_t js = 63u - (uint32_t)__builtin_clzll(okm);
+        p = lane_get(cx, js);
+        out = lane_get(cy, js);
+        while (p < seg_end && out <= B) {
+            if (!window())
+                return;
+        }
+    }
+#ifdef SZ_STREAM_DEBUG
+    {
+        unsigned long long dbg_t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_t1) :: "memory");
+        if (lane == 0)
+            atomicMax(flag + 1, (dbg_windows << 13) | (s & 8191u));  // most windows walked by a wave, its segment
+        (void)dbg_t0;
+    }
+#endif
 }
 
 // off[0] = body, off[n_frag] = n, everything between "not found"; entries[] = "no element starts here";
@@ -486,7 +602,7 @@ hipError_t launch_stream_index(const void *d_in, uint64_t n, uint32_t body, uint
     hipLaunchKernelGGL(stream_chunk_entries_kernel, dim3(n_chunk), dim3(64), 0, stream, (uint32_t)n, n_seg, seg_shift,
                        maps, centries, entries);
     hipLaunchKernelGGL(stream_boundaries_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, (uint32_t)ulen,
-                       n_seg, seg_shift, entries, off, d_result + 1);
+                       n_seg, seg_shift, entries, maps, chk, off, d_result + 1);
     return hipGetLastError();
 }
 

@@ -27,16 +27,23 @@
  * negative SZ_E* on failure; no exceptions cross this boundary; no CPU fallback -- without a
  * usable GPU every compute entry point returns SZ_ENODEV / SZ_EHIP.
  * Device entry points are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
- * default stream) and never synchronise.  The compress entry points keep a 64 MiB workspace per
- * (device, stream) for the three-waves-per-SIMD kernel; it is allocated by the first call on a stream
- * that is not being captured (a call made during graph capture before that simply uses the
- * one-wave kernel), so make one warm-up call before capturing a graph.  Which kernel runs is
- * chosen per launch from a sample of the data; environment SZ_KERNEL=single|dual forces one
- * (same output bytes either way).
+ * default stream) and never synchronise.  The compress entry points keep a 68 MiB workspace per
+ * (device, stream) for the kernels that take compressible launches (global hash tables, launch state,
+ * block queue); it is allocated by the first call on a stream that has enough blocks and is not being
+ * captured (a call made during graph capture before that simply uses the one-wave kernel), so make
+ * one warm-up call before capturing a graph; sz_release_stream_resources() frees it.  Which kernel
+ * runs is chosen per launch from a sample of the data (same output bytes whichever runs).
  *
- * Environment (all optional, read per call): SZ_KERNEL=single|dual forces a compress kernel;
- * SZ_SERIAL_UNCOMPRESS=1 makes sz_uncompress skip the parallel fragment index (single-wavefront
- * decode of the whole stream); SZ_TEST_SEG_SHIFT is a hook of the test-suite.
+ * Environment (all optional, read per call):
+ *   SZ_KERNEL  forces a compress kernel: `single` (one wave per block, table in LDS: what incompressible
+ *              launches get), `team` (two waves share a block and its LDS table + two waves per workgroup
+ *              with tables in global memory: what compressible launches get), `dual` (rounds 1-2's kernel
+ *              for compressible launches: three independent waves per workgroup; kept for comparison),
+ *              `route` (per block inside the launch: the single kernel hands blocks with a copy to `dual`).
+ *              Unset: the sampled choice between `single` and `team`.
+ *   SZ_SERIAL_UNCOMPRESS=1  makes sz_uncompress skip the parallel fragment index (single-wavefront decode).
+ *   SZ_TEST_SEG_SHIFT       a hook of the test-suite (segment size of the fragment index).
+ *   SZ_DEBUG_FLAGS          only read by diagnostic builds (-DSZ_ABLATION: timing ablations with wrong output).
  */
 #ifndef SNAPPY_HIP_H
 #define SNAPPY_HIP_H
