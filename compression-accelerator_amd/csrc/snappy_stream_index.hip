@@ -68,14 +68,24 @@ __device__ __forceinline__ uint32_t lane_shuffle(uint32_t v, uint32_t src_lane)
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src_lane & 63u) << 2), (int)v);
 }
 
+// minimum over the 64 lanes (every lane gets it): DPP inside the rows and across them -- six vector
+// instructions and one v_readlane instead of six dependent trips through the LDS crossbar (ds_bpermute: ~57
+// clocks each, tools/isacost.hip); lanes a DPP step has no source for keep the identity
 __device__ __forceinline__ uint32_t wave_min(uint32_t v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = lane_shuffle(v, (threadIdx.x & 63u) ^ (uint32_t)d);
-        v = o < v ? o : v;
+#define SZ_DPP_MIN(ctrl, rmask)                                                                                   \
+    {                                                                                                             \
+        const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, (ctrl), (rmask), 0xf, false); \
+        v = t_ < v ? t_ : v;                                                                                      \
     }
-    return v;
+    SZ_DPP_MIN(0x111, 0xf)  // row_shr:1
+    SZ_DPP_MIN(0x112, 0xf)  // row_shr:2
+    SZ_DPP_MIN(0x114, 0xf)  // row_shr:4
+    SZ_DPP_MIN(0x118, 0xf)  // row_shr:8  -> lane 15 of every row holds the row's minimum
+    SZ_DPP_MIN(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+    SZ_DPP_MIN(0x143, 0xc)  // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's minimum
+#undef SZ_DPP_MIN
+    return lane_get(v, 63);
 }
 
 // Window of 64 bytes at wb: for a chain of elements that enters it at lane l (byte wb + l),
