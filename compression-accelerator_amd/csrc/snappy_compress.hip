@@ -2437,7 +2437,11 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             }
             const uint32_t op = compress_one_block<0, true>(gtab, src + (uint64_t)b * in_stride, n,
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
+#ifdef SZ_EXP_COUNT
+            out_len[b] = op | 0x80000000u;  // (tools/rolecount.hip: a block done by a lone wave)
+#else
             out_len[b] = op;
+#endif
         }
         return;
     }
