@@ -1040,7 +1040,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                     "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
                                     "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1"
                                     : "+s"(S), "+s"(x), "=&s"(bit)
-                                    : "v"(X));
+                                    : "v"(X)
+                                    : "scc");  // (s_lshl_b64 and s_or_b64 write SCC)
                             } while (!(x & 64u));
                             TRACE(12);
                             const uint32_t s_l = x & 63u;  // the last start: the lane whose jump left the tile
