@@ -156,19 +156,26 @@ __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *
                 ref = (uint32_t)__builtin_ctzll(live);  // (live != 0 here)
             uint32_t rpos = lane_get(pos, ref);
             uint32_t mk = (rpos - seg_base) >> kChkShift;
+            bool hold = false;
             if (mk >= next_mark && rpos >= wb + 64) {
                 // the reference is about to leave a checkpoint far ahead of the hindmost parse: one of the two is
                 // reading payload as elements (a fake literal of kilobytes that stays inside the segment, or the
                 // parses that started inside a real one).  The one more hypotheses have joined is the better
                 // reference either way: where it is wrong, the true parse is one long element and needs no checkpoint.
+                // Until more parses stand at the hindmost position than with the reference, nothing is recorded: the
+                // hindmost ones reach the marks in between later, and early in a segment -- 64 parses, none joined yet
+                // -- a reference that read payload as a literal of 27 KiB would otherwise leave its end as the
+                // checkpoint of 27 marks (one text segment in a hundred: its boundaries pass then walked 455 windows).
                 const uint64_t hind = __ballot(active && pos == wb);
                 if (__builtin_popcountll(hind) > __builtin_popcountll(__ballot(active && pos == rpos))) {
                     ref = (uint32_t)__builtin_ctzll(hind);
                     rpos = wb;
                     mk = (rpos - seg_base) >> kChkShift;
+                } else {
+                    hold = true;
                 }
             }
-            if (mk >= next_mark) {
+            if (mk >= next_mark && !hold) {
                 const uint32_t rout = lane_get(out, ref);
                 if (lane == 0)
                     for (uint32_t j = next_mark; j <= mk; j++)
@@ -239,13 +246,31 @@ __global__ __launch_bounds__(64) void stream_chunk_maps_kernel(uint32_t n, uint3
 
 // The parse from p (bytes produced: out) up to the first element that starts at or past `until`,
 // recording in entries[] the first element that starts in each segment.  One wave, wave-uniform state.
+// `rows` (LDS) takes the maps of segments [row_s0, row_s0 + row_cnt) at the first look-up of one of them (all rows
+// in flight at once): every look-up would otherwise be a dependent trip to memory of this one wave.  (A stream of
+// incompressible fragments never looks a map up: its rows are not fetched.)
 __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, uint32_t n, uint32_t seg_shift,
                                               const uint2 *__restrict__ maps, const uint2 *__restrict__ chk,
                                               uint2 *__restrict__ entries, uint32_t &p, uint32_t &out,
-                                              uint32_t until, uint32_t lane)
+                                              uint32_t until, uint32_t lane, uint2 *rows, uint32_t row_s0,
+                                              uint32_t row_cnt)
 {
     const uint32_t kSeg = 1u << seg_shift;
     uint32_t last_seg = kBad;
+    bool rows_here = false;
+    auto map_of = [&](uint32_t s, uint32_t rel) -> uint2 {  // (s, rel wave-uniform)
+        if (s - row_s0 >= row_cnt)
+            return maps[(size_t)s * 64 + rel];
+        if (!rows_here) {
+            __syncthreads();  // (single-wave workgroup: orders the LDS accesses of its lanes)
+#pragma unroll 16
+            for (uint32_t i = 0; i < row_cnt; i++)
+                rows[i * 64 + lane] = maps[(size_t)(row_s0 + i) * 64 + lane];
+            __syncthreads();
+            rows_here = true;
+        }
+        return rows[(s - row_s0) * 64 + rel];
+    };
     while (p < until) {
         const uint32_t s = p >> seg_shift;
         const uint32_t seg_base = s * kSeg;
@@ -256,7 +281,7 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
         }
         const uint32_t rel = p - seg_base;
         if (rel < 64) {  // the segment's map covers the rest of the segment
-            const uint2 m = maps[(size_t)s * 64 + rel];
+            const uint2 m = map_of(s, rel);
             const uint32_t ex = uni(m.x), os = uni(m.y);
             if (ex == kBad)
                 return false;
@@ -293,7 +318,7 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
                     const uint2 c = chk[(size_t)s * n_chk + mark];
                     if (uni(c.x) == p) {
                         // (the checkpoint's hypothesis: its exit and the bytes it has produced by then and by here)
-                        const uint2 m = maps[(size_t)s * 64 + (uni(c.y) >> 26)];
+                        const uint2 m = map_of(s, uni(c.y) >> 26);
                         if (uni(m.x) == kBad)
                             return false;
                         out += uni(m.y) - (uni(c.y) & 0x3ffffffu);
@@ -335,12 +360,26 @@ __global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__res
                                                             uint2 *__restrict__ entries, uint2 *__restrict__ centries,
                                                             uint32_t *__restrict__ result)
 {
+    // One wave, and every step's look-up depends on the step before: the tables it reads are brought into LDS in
+    // whole rows first (all 64 entries of a chunk map / of a segment map, many rows in flight at once), so that a
+    // step costs an LDS read instead of a trip to memory (~2 us each: the rows were written by other XCDs).
+    constexpr uint32_t kCmGroup = 16;
+    __shared__ ChunkMap cm_rows[kCmGroup * 64];  // chunk maps of kCmGroup chunks
+    __shared__ uint2 seg_rows[kChunkSegs * 64];  // segment maps of the chunk that is being walked
     const uint32_t kSeg = 1u << seg_shift;
     const uint32_t lane = threadIdx.x;
     const uint32_t n_chunk = (n_seg + kChunkSegs - 1) / kChunkSegs;
     uint32_t p = body, out = 0;
     bool ok = true;
     for (uint32_t c = 0; c < n_chunk && ok; c++) {
+        if (c % kCmGroup == 0) {
+            __syncthreads();  // (the rows of the group before have been read)
+            const uint32_t cnt = n_chunk - c < kCmGroup ? n_chunk - c : kCmGroup;
+#pragma unroll 16
+            for (uint32_t i = 0; i < cnt; i++)
+                cm_rows[i * 64 + lane] = cmaps[(size_t)(c + i) * 64 + lane];
+            __syncthreads();
+        }
         const uint64_t cb64 = (uint64_t)c * kChunkSegs * kSeg;
         const uint64_t ce64 = cb64 + (uint64_t)kChunkSegs * kSeg;
         const uint32_t chunk_base = (uint32_t)cb64, chunk_end = ce64 < n ? (uint32_t)ce64 : n;
@@ -348,7 +387,7 @@ __global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__res
         if (p < chunk_end) {
             bool regular = false;
             if (p - chunk_base < 64) {
-                const ChunkMap cm = cmaps[(size_t)c * 64 + (p - chunk_base)];
+                const ChunkMap cm = cm_rows[(c % kCmGroup) * 64 + (p - chunk_base)];
                 if (uni(cm.st) == kStRun) {  // the whole chunk through near entries: pass 2c fills its entries
                     ce = make_uint2(p, out);
                     p = uni(cm.pos);
@@ -356,8 +395,10 @@ __global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__res
                     regular = true;
                 }
             }
-            if (!regular)
-                ok = walk_segments(in, n, seg_shift, maps, chk, entries, p, out, chunk_end, lane);
+            if (!regular) {
+                const uint32_t s0 = c * kChunkSegs, cnt = n_seg - s0 < kChunkSegs ? n_seg - s0 : kChunkSegs;
+                ok = walk_segments(in, n, seg_shift, maps, chk, entries, p, out, chunk_end, lane, seg_rows, s0, cnt);
+            }
         }
         if (lane == 0)
             centries[c] = ce;
@@ -426,9 +467,12 @@ __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__
     const uint32_t seg_end = seg_base + kSeg < n ? seg_base + kSeg : n;
     const uint32_t n_chk = kSeg >> kChkShift;
     const uint2 *my_chk = chk + (size_t)s * n_chk;
-    uint32_t delta = 0, jm = kBad;  // true output position of checkpoint j = (chk[j].y & 0x3ffffff) + delta, for j >= jm
-    uint32_t rid = 0;               // ... of the hypothesis the parse has met (chk[j].y >> 26 == rid)
-    uint32_t mark = 0;              // the next KiB mark ahead of the walk
+    // The segment's checkpoints, one per lane (n_chk <= 64): position, bytes produced in its hypothesis' frame, hypothesis
+    const uint2 kc = lane < n_chk ? my_chk[lane] : make_uint2(kBad, 0);
+    const uint32_t kx = kc.x, kout = kc.y & 0x3ffffffu, kid = kc.y >> 26;
+    uint32_t delta = 0, jm = kBad;  // true output position of checkpoint j = kout(j) + delta, for j >= jm with kid(j) == rid
+    uint32_t rid = 0;               // the hypothesis the parse has met
+    bool remet = false;             // the last window changed (rid, delta, jm)
     // one window of the walk: the elements that start in [p, p + 62] and inside the segment; records the ones that
     // start on a boundary; false: a flag was raised (the caller decodes serially)
     auto window = [&]() -> bool {
@@ -474,40 +518,32 @@ __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__
                 atomicOr(flag, 2u);
             return false;
         }
-        // a KiB mark inside this window: is this parse's first element at or past it hypothesis 0's (the
-        // checkpoint of that mark)?  Then the parse stands THERE: the rest of the segment is looked up.
-        // (a checkpoint is AN element start of hypothesis 0 shortly behind its mark -- the first one pass 1 looked
-        // at, not necessarily the first one there is --: the parses have met if it is an element start of this
-        // parse too)
-        while (jm == kBad && mark < n_chk) {
-            const uint32_t cxm = uni(my_chk[mark].x);
-            const uint32_t wend = p + e_last + lane_get(e.size, e_last);  // where this window's chain ends
-            if (cxm == kBad || cxm >= wend)
-                break;  // no checkpoint for this mark (hypothesis 0 has ended), or it lies ahead of this window
-            if (cxm >= p && cxm - p < 64 && ((Mm >> (cxm - p)) & 1)) {
-                const uint32_t cym = uni(my_chk[mark].y);
-                jm = mark;
-                rid = cym >> 26;
-                delta = lane_get(start, cxm - p) - (cym & 0x3ffffffu);
-            } else {
-                mark++;  // behind this parse, or not one of its element starts: try the next mark's
+        // Does this parse stand on a checkpoint in this window -- is a checkpoint's position one of its element
+        // starts?  (A checkpoint is AN element start of its hypothesis shortly behind its KiB mark.)  Then the parse IS
+        // that hypothesis from there on, and what lies ahead is looked up among that hypothesis' checkpoints.  Tested
+        // in every window, also behind the first meeting: pass 1 changes the hypothesis it records when the one it
+        // followed stands far ahead of most others (a long literal), and a walk that started from the old one's last
+        // checkpoint would otherwise go on to the segment's end (455 windows in 1 % of a text stream's segments).
+        {
+            const uint32_t relc = kx - p;
+            const bool at = kx != kBad && kx >= p && relc < 64u && ((Mm >> (relc & 63u)) & 1ull);
+            const uint64_t meet = ballot64(at);
+            if (meet) {
+                const uint32_t jj = 63u - (uint32_t)__builtin_clzll(meet);  // the last of them
+                const uint32_t id = lane_get(kid, jj);
+                if (jm == kBad || id != rid) {
+                    rid = id;
+                    jm = jj;
+                    delta = lane_get(start, lane_get(relc, jj)) - lane_get(kout, jj);
+                    remet = true;
+                }
             }
         }
         out += lane_get(incl, 63);
         p += e_last + lane_get(e.size, e_last);
         return true;
     };
-    // ---- from the entry until the parse stands on a checkpoint of hypothesis 0 (or leaves the segment)
-    {
-        const uint32_t j0 = (p - seg_base) >> kChkShift;
-        if (uni(my_chk[j0].x) == p) {  // (an entry on a checkpoint, e.g. at the segment's first byte)
-            const uint32_t cy0 = uni(my_chk[j0].y);
-            jm = j0;
-            rid = cy0 >> 26;
-            delta = out - (cy0 & 0x3ffffffu);
-        }
-    }
-    mark = ((p - seg_base) >> kChkShift) + 1;  // the next KiB mark ahead
+    // ---- from the entry until the parse stands on a checkpoint (or leaves the segment)
     while (jm == kBad && p < seg_end) {
         if (!window())
             return;
@@ -515,25 +551,33 @@ __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__
     if (jm == kBad)
         return;  // the whole segment was walked
     // ---- the boundaries behind the meeting point: look each one up among the checkpoints, walk the KiB before it
-    const uint2 m0 = maps[(size_t)s * 64 + rid];  // that hypothesis: (exit, bytes produced) -- bytes at the exit = m0.y + delta
-    const uint32_t out_exit = uni(m0.y) + delta;
-    const uint32_t cyr = lane < n_chk ? my_chk[lane].y : 0u;
-    const uint32_t cx = (lane < n_chk && (cyr >> 26) == rid) ? my_chk[lane].x : kBad;  // (n_chk <= 64; one hypothesis' only)
-    const uint32_t cy = (cyr & 0x3ffffffu) + delta;
-    for (uint32_t B = (out + 0xffffu) & ~0xffffu; B < out_exit && B < ulen; B += 0x10000u) {
-        if (B == 0)
+    for (uint32_t B = (out + 0xffffu) & ~0xffffu;;) {
+        const uint2 m0 = maps[(size_t)s * 64 + rid];  // that hypothesis: (exit, bytes produced) -- bytes at the exit = m0.y + delta
+        const uint32_t out_exit = uni(m0.y) + delta;
+        if (!(B < out_exit && B < ulen))
+            break;
+        if (B == 0) {
+            B += 0x10000u;
             continue;
-        // the last checkpoint at or behind the meeting point whose element starts at or before B
-        const uint64_t okm = ballot64(lane >= jm && cx != kBad && cy <= B);
-        if (okm == 0)
-            break;  // (cannot happen: checkpoint jm qualifies)
-        const uint32_t js = 63u - (uint32_t)__builtin_clzll(okm);
-        p = lane_get(cx, js);
-        out = lane_get(cy, js);
-        while (p < seg_end && out <= B) {
+        }
+        // the last checkpoint of that hypothesis at or behind the meeting point whose element starts at or before B
+        const uint32_t cy = kout + delta;
+        const uint64_t okm = ballot64(lane >= jm && kx != kBad && kid == rid && cy <= B);
+        if (okm != 0) {
+            const uint32_t js = 63u - (uint32_t)__builtin_clzll(okm);
+            const uint32_t pj = lane_get(kx, js);
+            if (pj > p) {  // (never back: the walk may already stand behind it)
+                p = pj;
+                out = lane_get(cy, js);
+            }
+        }
+        remet = false;
+        while (p < seg_end && out <= B && !remet) {
             if (!window())
                 return;
         }
+        if (!remet)
+            B += 0x10000u;  // (else: the same boundary again, among the checkpoints of the hypothesis just met)
     }
 #ifdef SZ_STREAM_DEBUG
     {

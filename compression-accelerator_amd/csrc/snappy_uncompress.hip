@@ -19,6 +19,12 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
     uint32_t n_streams, uint8_t *dst, uint64_t dst_stride, uint32_t *__restrict__ out_len,
     int32_t *__restrict__ status)
 {
+    // Output of one window of elements, assembled in LDS before it goes to memory in whole 16-byte pieces:
+    // [0, kHist) the last bytes written before this window (what an overlapping copy at the window's start can
+    // reach), [kHist, kHist + kWinCap) this window's elements.  A window holds at most 21 three-byte copies of 64
+    // bytes and one more element of <= 64: 1 408 bytes.
+    constexpr uint32_t kHist = 64, kWinCap = 1472;
+    __shared__ __attribute__((aligned(16))) uint8_t wbuf[kHist + kWinCap];
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_streams)
@@ -108,7 +114,25 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             st = kStatusCorrupt;
             break;
         }
-        {   // the last element may reach past the window: the next window starts where it really ends
+        // A literal of more than 64 bytes does not go through the window's buffer: the window ends in front of
+        // it, and a window that begins with one is that literal alone, input to output by all lanes.
+        const uint64_t BL = __ballot(kind_v == 0 && olen_v > 64) & Pm;
+        if (BL & 1ull) {
+            const uint32_t len = lane_get(olen_v, 0), hdr = lane_get(aux_v, 0);
+            if ((uint64_t)op + len > ulen) {
+                st = kStatusCorrupt;
+                break;
+            }
+            wave_copy<6>(out + op, in + ip + hdr, len, lane);
+            wbuf[lane] = in[ip + hdr + len - 64 + lane];  // (what a copy right behind it can reach)
+            ip += hdr + len;
+            op += len;
+            continue;
+        }
+        if (BL) {
+            j = ctz64(BL);
+            Pm &= (1ull << j) - 1ull;
+        } else {  // the last element may reach past the window: the next window starts where it really ends
             const uint32_t e_last = 63u - (uint32_t)__builtin_clzll(Pm);
             j = e_last + lane_get(size_v, e_last);  // (sizes of valid elements fit: n < 2^31)
         }
@@ -118,7 +142,7 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
         const uint32_t incl = wave_inclusive_sum(olen);
         const uint32_t o_rel = incl - olen;  // offset inside this window's output
         const uint32_t total = lane_get(incl, 63);
-        if ((uint64_t)op + total > ulen) {
+        if ((uint64_t)op + total > ulen || total > kWinCap) {  // (more than kWinCap: not reached, see above)
             st = kStatusCorrupt;
             break;
         }
@@ -128,21 +152,20 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             break;
         }
         // A copy whose source ends before this window's output begins ("far") depends on nothing that
-        // is produced here, nor does a literal: those are all done at once, one element per lane,
-        // four bytes per step.  Copies that read this window's own output ("near") follow in order.
+        // is produced here, nor does a literal: those are all done at once, one element per lane, into the
+        // window's buffer.  Copies that read this window's own output ("near") follow in order, LDS to LDS:
+        // no trip to memory per copy.
         const bool far_copy = is_copy && aux_v >= o_rel + olen;
         const bool near_copy = is_copy && !far_copy;
-        const bool small_lit = is_elem && kind_v == 0 && olen <= 64;
-        const bool big_lit = is_elem && kind_v == 0 && olen > 64;
+        const bool small_lit = is_elem && kind_v == 0;
+        uint8_t *const win = wbuf + kHist;
         {
             const bool par = far_copy || small_lit;
             const uint8_t *sp = small_lit ? in + ip + lane + aux_v : out + op + o_rel - aux_v;
-            uint8_t *dp = out + op + o_rel;
+            uint8_t *dp = win + o_rel;
             const uint32_t mylen = par ? olen : 0u;
             // 16 bytes per step while any element has that many left, then the rest in one step: few
             // predicated memory instructions for the short elements that dominate.
-            // (sources and destinations of different lanes never overlap: far copies end before the
-            // window's output begins, literals come from the input)
             uint32_t i = 0;
             while (__ballot(i + 16 <= mylen) != 0) {
                 if (i + 16 <= mylen) {
@@ -165,19 +188,30 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             if (c4) { __builtin_memcpy(dp + i, &a4, 4); __builtin_memcpy(dp + mylen - 4, &b4, 4); }
             if (c1) { dp[i] = a1; dp[i + (r >> 1)] = m1; dp[mylen - 1] = b1; }
         }
-        // literals longer than 64 bytes: cooperative copies (their data comes from the input)
-        for (uint64_t B = __ballot(big_lit); B; B &= B - 1) {
-            const uint32_t e = ctz64(B);
-            wave_copy<6>(out + op + lane_get(o_rel, e), in + ip + e + lane_get(aux_v, e), lane_get(olen_v, e), lane);
-        }
-        // near copies, in stream order (they may read what the steps above and each other wrote)
+        // near copies, in stream order (they may read what the steps above and each other wrote, and up to
+        // kHist bytes of what was written before this window)
         for (uint64_t N = __ballot(near_copy); N; N &= N - 1) {
             const uint32_t e = ctz64(N);
-            const uint32_t len = lane_get(olen_v, e), off = lane_get(aux_v, e), o = op + lane_get(o_rel, e);
+            const uint32_t len = lane_get(olen_v, e), off = lane_get(aux_v, e), o = lane_get(o_rel, e);
             // (off >= len: plain copy; else the last `off` bytes repeat -- the division only then)
             const uint32_t k = off >= len ? lane : lane % off;
             if (lane < len)
-                out[o + lane] = out[o - off + k];
+                win[o + lane] = wbuf[kHist + o - off + k];  // (off < o + len <= o + 64: inside the buffer)
+        }
+        // the window's bytes go out: 16 per lane and step, the last < 16 one per lane
+        for (uint32_t i = 16u * lane; i + 16u <= total; i += 1024u) {
+            u32x4 v;
+            __builtin_memcpy(&v, win + i, 16);
+            __builtin_memcpy(out + op + i, &v, 16);
+        }
+        {
+            const uint32_t t0 = total & ~15u;
+            if (lane < total - t0)
+                out[op + t0 + lane] = win[t0 + lane];
+        }
+        {   // the last kHist bytes written so far move to the front of the buffer (read by all lanes, then written)
+            const uint8_t hb = wbuf[total + lane];
+            wbuf[lane] = hb;
         }
         op += total;
         if (st != 0)
