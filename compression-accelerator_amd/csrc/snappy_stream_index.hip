@@ -138,12 +138,19 @@ __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *
     uint32_t pos = seg_base + lane, out = 0;  // hypothetical parse number `lane`
     uint32_t next_mark = 0;                   // the next KiB mark without a checkpoint
     uint32_t ref = 0;                         // the hypothesis whose checkpoints are being recorded
+    // Within a few windows the parses that matter stand on ONE position and move together; the loop is bound by
+    // instruction issue (seven waves per SIMD, ~150 instructions per window), so that common case skips what it
+    // does not need: `pk` = the hindmost position when it is known without a reduction over the lanes (only the
+    // parses there moved in the window before, and nobody lies below where they went), `ref_here` = the reference
+    // is one of them -- then no mark is reached before (pk - seg_base) >> kChkShift says so.
+    uint32_t pk = kBad;
+    bool ref_here = false;
     for (;;) {
         const bool active = pos < seg_end;  // (kBad and exits are >= seg_end)
         if (__ballot(active) == 0)
             break;
-        const uint32_t wb = uni(wave_min(active ? pos : kBad));
-        {
+        const uint32_t wb = pk != kBad ? pk : uni(wave_min(active ? pos : kBad));
+        if (!(pk != kBad && ref_here && ((wb - seg_base) >> kChkShift) < next_mark)) {
             // Checkpoints of ONE hypothesis, the reference: at every KiB mark the first of its element starts that
             // this loop sees at or past the mark, the bytes it has produced by then, and its number (bits 26..31:
             // a segment produces < 64 MiB).  Hypothesis 0 is the reference while it lives; a hypothesis that runs
@@ -182,14 +189,24 @@ __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *
                         my_chk[j] = make_uint2(rpos, (rout & 0x3ffffffu) | (ref << 26));
                 next_mark = mk + 1;
             }
+            ref_here = rpos == wb;
         }
         uint32_t E, O;
         window_map(in, wb, seg_end, n, lane, E, O);
         const uint32_t rel = pos - wb;
         const uint32_t e = lane_shuffle(E, rel), o = lane_shuffle(O, rel);
-        if (active && rel < 64) {  // (an element is >= 2 bytes: every parse in the window moves on)
+        const bool moves = active && rel < 64;  // (an element is >= 2 bytes: every parse in the window moves on)
+        const uint64_t others = ballot64(moves && rel != 0);
+        if (moves) {
             out += o;
             pos = e == kBad ? kBad : wb + e;
+        }
+        pk = kBad;
+        if (others == 0) {  // only the parses at wb moved: to wb + E(0), all of them
+            const uint32_t ex = lane_get(E, 0);
+            const uint32_t np = ex == kBad ? kBad : wb + ex;
+            if (np < seg_end && ballot64(pos < np) == 0)  // (parses that are out of the segment lie above every np)
+                pk = np;
         }
     }
     maps[(size_t)s * 64 + lane] = make_uint2(pos, out);
