@@ -14,8 +14,10 @@
 //      the true parse from chunk to chunk, and the chunks' segments get their entries in parallel again
 //      (details at the kernels: a chunk that the parse enters far from a segment's start is walked by
 //      that one wave, runs of equal-sized elements 64 at a time).
-//   3. one wave per segment walks its elements from that entry and records the compressed offset of
-//      every element that starts on a 64 KiB output boundary; an element that straddles a boundary
+//   3. one wave per segment follows the parse from that entry until it stands on a checkpoint that pass 1
+//      left (one per KiB, of one of its hypothetical parses), looks every 64 KiB output boundary of the
+//      segment up among the checkpoints and walks only the KiB in front of it; it records the compressed
+//      offset of every element that starts on a boundary; an element that straddles a boundary
 //      means the stream was not produced fragment by fragment: the caller then decodes serially.
 // Streams of every stock Snappy compressor (64 KiB fragments) qualify.  Nothing here moves payload
 // bytes; the bound is instruction issue of the tag decode (about 100 instructions per 64 bytes).

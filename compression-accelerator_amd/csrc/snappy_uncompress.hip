@@ -6,8 +6,10 @@ namespace szk {
 
 // -------------------------------------------------------------------- decompression (8f-1)
 
-// One wavefront per raw stream.  Elements are parsed serially (the format has no index); the
-// bytes of each element are moved by all 64 lanes.  Copies read back this wave's own earlier
+// One wavefront per raw stream.  Elements are parsed serially (the format has no index), 64 compressed
+// bytes (a window) at a time; the window's output is assembled in LDS -- one element per lane for literals
+// and for copies of bytes written before the window, then the copies that read the window's own output,
+// in order -- and stored in whole 16-byte pieces.  Copies of older bytes read back this wave's own earlier
 // stores to global memory: same wave, same address path, program order.
 // Two ways to name the streams: fixed stride + per-stream length, each a raw stream with its own
 // preamble (src_off == nullptr); or the fragments of ONE packed stream, fragment b = bytes
