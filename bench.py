@@ -16,7 +16,8 @@ code.  Under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 Headline workload (config.workload): C3 = consecutive 64 KiB windows of the infinite tiling of
 data/randomASCII.txt (BASELINE.json configs[2], the one the north-star target is quoted on);
 --blocks-per-gpu 32768 (2 GiB per GPU) so that N=8 is config C4's 16 GiB.  Short passes over the
-text (C2-like), low-entropy (C5) and mixed (C4 mix) workloads are reported in "workloads".
+text (C2-like), low-entropy (C5) and mixed (C4 mix) workloads are reported in "workloads"; "one_stream" is the
+next rows' number (one 1 GiB raw stream compressed + packed, then decoded from its bytes alone).
 Every block of every pass is compared with the oracle after the timed region.
 """
 import argparse
@@ -225,6 +226,46 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
             "decompress": dec, "layout": layout}
 
 
+def one_stream(P, kind, n_blocks, device, reps=3):
+    """The rows next to the hot path on ONE raw stream resident in HBM: fragments compressed and
+    packed into `varint32(n) + bodies` on the device, then decoded from nothing but those bytes (fragment offsets
+    found by the stream index).  Kernel-side times (events on the launch stream), best of `reps`; round trip checked."""
+    import torch
+    src = make_input(kind, 0, n_blocks, device)
+    n = n_blocks * BLOCK
+    hdr, v = [], n
+    while v >= 0x80:
+        hdr.append(0x80 | (v & 0x7f))
+        v >>= 7
+    hdr.append(v)
+    slots = torch.empty(n_blocks * P.SLOT_STRIDE, dtype=torch.uint8, device=device)
+    lens = torch.empty(n_blocks, dtype=torch.int32, device=device)
+    packed = torch.empty(len(hdr) + n_blocks * P.SLOT_STRIDE + 64, dtype=torch.uint8, device=device)
+    offs = torch.empty(n_blocks + 1, dtype=torch.int64, device=device)
+    back = torch.empty(n, dtype=torch.uint8, device=device)
+    packed[:len(hdr)] = torch.tensor(hdr, dtype=torch.uint8, device=device)
+    t_c, t_d, st = [], [], None
+    for i in range(reps + 1):
+        a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        a.record()
+        P.compress_stream(src, n, slots=slots, lens=lens)
+        P.pack_stream(slots, P.SLOT_STRIDE, lens, n_blocks, base=len(hdr), packed=packed, offsets=offs)
+        b.record()
+        total = int(offs[n_blocks].item())
+        b2 = torch.cuda.Event(enable_timing=True)
+        b2.record()
+        _, st = P.uncompress_stream(packed, total, len(hdr), n, dst=back)
+        c.record()
+        torch.cuda.synchronize()
+        if i:  # (the first pass warms up: workspaces, code objects)
+            t_c.append(a.elapsed_time(b))
+            t_d.append(b2.elapsed_time(c))
+    ok = st.cpu().numpy().tolist() == [0, 0, 0] and bool(torch.equal(back, src))
+    return {"workload": kind, "uncompressed_bytes": n, "stream_bytes": total,
+            "compress_and_pack_GBps": round(n / (min(t_c) * 1e-3) / 1e9, 2),
+            "indexed_decode_GBps": round(n / (min(t_d) * 1e-3) / 1e9, 2), "round_trip": ok}
+
+
 def copy_roof(n_bytes, device, reps=10):
     """A plain device-to-device copy of as many bytes as the headline workload reads (torch's copy kernel, the
     same process, the same box, HIP events on the stream it runs on): what this part moves when a kernel
@@ -406,6 +447,10 @@ def rank_main(args):
             if r["layout"] is not None:
                 extras[kind].update(r["layout"])
 
+    stream_row = None
+    if not args.no_extra and rank == 0 and world == 1:
+        stream_row = one_stream(P, "text", 16384, device)
+
     bad_all = main_res["blocks_differing_from_oracle"] + sum(v["blocks_differing_from_oracle"] for v in extras.values())
     if dist_on:
         t = torch.tensor([bad_all], device=device, dtype=torch.int64)
@@ -460,6 +505,7 @@ def rank_main(args):
                          "peak_source": "MI355X HBM3E spec (MI355X_MICROARCH.md); device reports %s, %d CUs"
                                         % (props.name, props.multi_processor_count)},
             "workloads": extras,
+            "one_stream": stream_row,
         }
         if main_res["layout"] is not None:
             line.update(main_res["layout"])  # rank 0's view of the all_gather result
