@@ -46,9 +46,8 @@ struct Elem {
     uint32_t size, olen;
     bool ok;
 };
-__device__ __forceinline__ Elem element_at(const uint8_t *__restrict__ in, uint32_t p, uint32_t n)
+__device__ __forceinline__ Elem element_of(uint64_t x, uint32_t p, uint32_t n)  // x = the 8 bytes at p
 {
-    const uint64_t x = ld64(in + p);
     const uint32_t tag = (uint32_t)x & 0xffu;
     const uint32_t extra = (uint32_t)(x >> 8);
     const uint32_t kind = tag & 3u, l6 = tag >> 2;
@@ -63,6 +62,10 @@ __device__ __forceinline__ Elem element_at(const uint8_t *__restrict__ in, uint3
     e.size = (uint32_t)size;
     e.olen = olen;
     return e;
+}
+__device__ __forceinline__ Elem element_at(const uint8_t *__restrict__ in, uint32_t p, uint32_t n)
+{
+    return element_of(ld64(in + p), p, n);
 }
 
 __device__ __forceinline__ uint32_t lane_shuffle(uint32_t v, uint32_t src_lane)
@@ -94,14 +97,18 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v)
 // E = offset from wb at which the chain leaves the window (>= 64), or (< 64) the offset of the first
 // element start at or past `limit` (the end of the segment or of the stream: chains stop there, so
 // that a segment's exit is exactly the next segment's entry), or kBad; O = bytes produced on the way.
-__device__ __forceinline__ void window_map(const uint8_t *__restrict__ in, uint32_t wb, uint32_t limit, uint32_t n,
-                                           uint32_t lane, uint32_t &E, uint32_t &O)
+// (`bytes` = the window's bytes where they are read from: `in + wb`, or a copy of that stretch of the stream in LDS)
+template <typename BytePtr>
+__device__ __forceinline__ void window_map_from(BytePtr bytes, uint32_t wb, uint32_t limit, uint32_t n,
+                                                uint32_t lane, uint32_t &E, uint32_t &O)
 {
     const uint32_t p = wb + lane;
     E = lane;  // at or past the limit: stays where it is
     O = 0;
     if (p < limit) {
-        const Elem e = element_at(in, p, n);
+        uint64_t x;
+        __builtin_memcpy(&x, bytes + lane, 8);
+        const Elem e = element_of(x, p, n);
         E = e.ok ? lane + e.size : kBad;
         O = e.ok ? e.olen : 0u;
     }
@@ -114,6 +121,11 @@ __device__ __forceinline__ void window_map(const uint8_t *__restrict__ in, uint3
             E = e2;
         }
     }
+}
+__device__ __forceinline__ void window_map(const uint8_t *__restrict__ in, uint32_t wb, uint32_t limit, uint32_t n,
+                                           uint32_t lane, uint32_t &E, uint32_t &O)
+{
+    window_map_from(in + wb, wb, limit, n, lane, E, O);
 }
 
 // ---- 1. segment maps
@@ -228,6 +240,7 @@ __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *
 // entries[s] = (position, bytes produced) where the true parse enters segment s, (kBad, 0) where no
 // element starts in the segment; result[0] = 0 if the stream parses cleanly to its end.
 static constexpr uint32_t kChunkSegs = 64;
+static constexpr uint32_t kFarChunks = 128;  // 16-byte pieces of the stream the serial pass keeps in LDS while it walks windows
 static constexpr uint32_t kStRun = 0, kStFar = 1, kStBad = 2;
 
 struct ChunkMap {
@@ -263,6 +276,14 @@ __global__ __launch_bounds__(64) void stream_chunk_maps_kernel(uint32_t n, uint3
     cmaps[(size_t)c * 64 + lane] = ChunkMap{pos, out, st, 0};
 }
 
+#ifdef SZ_STREAM_DEBUG
+__device__ unsigned long long g_res_dbg[16];  // (debug builds: counts and clocks of the serial pass; tools/streamdbg.py)
+#define RES_COUNT(i, v) do { if (lane == 0) g_res_dbg[i] += (v); } while (0)
+#define RES_CLOCK(t) unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory")
+#else
+#define RES_COUNT(i, v) do { } while (0)
+#define RES_CLOCK(t) do { } while (0)
+#endif
 // The parse from p (bytes produced: out) up to the first element that starts at or past `until`,
 // recording in entries[] the first element that starts in each segment.  One wave, wave-uniform state.
 // `rows` (LDS) takes the maps of segments [row_s0, row_s0 + row_cnt) at the first look-up of one of them (all rows
@@ -272,7 +293,7 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
                                               const uint2 *__restrict__ maps, const uint2 *__restrict__ chk,
                                               uint2 *__restrict__ entries, uint32_t &p, uint32_t &out,
                                               uint32_t until, uint32_t lane, uint2 *rows, uint32_t row_s0,
-                                              uint32_t row_cnt)
+                                              uint32_t row_cnt, uint8_t *far_bytes, uint32_t &run_size)
 {
     const uint32_t kSeg = 1u << seg_shift;
     uint32_t last_seg = kBad;
@@ -281,14 +302,23 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
         if (s - row_s0 >= row_cnt)
             return maps[(size_t)s * 64 + rel];
         if (!rows_here) {
+            RES_CLOCK(tf0);
             __syncthreads();  // (single-wave workgroup: orders the LDS accesses of its lanes)
 #pragma unroll 16
             for (uint32_t i = 0; i < row_cnt; i++)
                 rows[i * 64 + lane] = maps[(size_t)(row_s0 + i) * 64 + lane];
             __syncthreads();
             rows_here = true;
+#ifdef SZ_STREAM_DEBUG
+            RES_CLOCK(tf1);
+            RES_COUNT(7, tf1 - tf0);
+#endif
         }
-        return rows[(s - row_s0) * 64 + rel];
+        uint2 m = rows[(s - row_s0) * 64 + rel];
+        // (kept apart from the load of the other branch: merged, the two become ONE load through a generic pointer,
+        // which waits like a load from memory -- and for the store to entries[] in front of it: 930 clocks a step)
+        asm volatile("" : "+v"(m.x), "+v"(m.y));
+        return m;
     };
     while (p < until) {
         const uint32_t s = p >> seg_shift;
@@ -300,6 +330,7 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
         }
         const uint32_t rel = p - seg_base;
         if (rel < 64) {  // the segment's map covers the rest of the segment
+            RES_COUNT(0, 1);
             const uint2 m = map_of(s, rel);
             const uint32_t ex = uni(m.x), os = uni(m.y);
             if (ex == kBad)
@@ -310,9 +341,15 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
         }
         // far from the segment's start: the element at p, and -- lane k -- the ones at p + k * size,
         // as long as they have the same size (what a run of equal literals or copies looks like)
-        const Elem e0 = element_at(in, p, n);
-        const uint32_t size0 = uni(e0.size);
-        if (!__builtin_amdgcn_readfirstlane(e0.ok ? 1 : 0))
+        // (lane k looks at p + k * the size of the run before right away: when this element has that size again --
+        // a stream of incompressible fragments is one ~64 KiB literal after the other -- the run costs one trip to
+        // memory instead of two)
+        const uint64_t qs64 = (uint64_t)p + (uint64_t)lane * run_size;
+        const bool ins = qs64 < until;
+        const uint32_t qs = ins ? (uint32_t)qs64 : p;
+        const Elem es = element_at(in, qs, n);
+        const uint32_t size0 = lane_get(es.size, 0);
+        if (!lane_get(es.ok ? 1u : 0u, 0))
             return false;
         if (size0 < 64) {
             // small elements (the inside of a compressible fragment): 64-byte window steps until the
@@ -322,9 +359,33 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
             const uint32_t n_chk = kSeg >> kChkShift;
             uint32_t mark = ((p - seg_base) >> kChkShift) + 1;  // the next KiB mark ahead
             bool merged = false;
+            RES_COUNT(1, 1);
+            RES_CLOCK(tq0);
+            // (every window's bytes would be a dependent trip to memory of this one wave -- ~1 us, two dozen windows
+            // until a checkpoint --: 2 KiB of the stream from p on are brought into LDS in one trip instead)
+            uint32_t b0 = kBad, bend = 0;  // far_bytes holds stream bytes [b0, bend)
             while (p < seg_end) {
                 uint32_t E, O;
-                window_map(in, p, seg_end, n, lane, E, O);
+                RES_COUNT(2, 1);
+                if (!(p >= b0 && p + 72u <= bend) && n + 8u - p >= 72u) {  // (the caller's buffer is readable to n + 8)
+                    const uint32_t avail = n + 8u - p;
+                    const uint32_t nck = avail / 16u < kFarChunks ? avail / 16u : kFarChunks;
+                    __syncthreads();
+#pragma unroll
+                    for (uint32_t k = 0; k < kFarChunks; k += 64) {
+                        if (k + lane < nck) {
+                            const u32x4 v = ld128(in + p + 16u * (k + lane));
+                            __builtin_memcpy(far_bytes + 16u * (k + lane), &v, 16);
+                        }
+                    }
+                    __syncthreads();
+                    b0 = p;
+                    bend = p + 16u * nck;
+                }
+                if (p >= b0 && p + 72u <= bend)
+                    window_map_from(far_bytes + (p - b0), p, seg_end, n, lane, E, O);
+                else
+                    window_map(in, p, seg_end, n, lane, E, O);
                 const uint32_t ex = lane_get(E, 0), os = lane_get(O, 0);
                 if (ex == kBad)
                     return false;
@@ -349,12 +410,20 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
                 }
             }
             (void)merged;
+#ifdef SZ_STREAM_DEBUG
+            RES_CLOCK(tq1);
+            RES_COUNT(8, tq1 - tq0);
+#endif
             continue;
         }
+        RES_COUNT(3, 1);
         const uint64_t q64 = (uint64_t)p + (uint64_t)lane * size0;
         const bool inside = q64 < until;  // (until <= n)
         const uint32_t q = inside ? (uint32_t)q64 : p;
-        const Elem e = element_at(in, q, n);
+        Elem e = es;  // (size0 == run_size: q64 == qs64, the elements are the ones already looked at)
+        if (size0 != run_size)
+            e = element_at(in, q, n);
+        run_size = size0;
         const uint64_t good = ballot64(inside && e.ok && e.size == size0);
         const uint32_t cnt = good == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~good);  // >= 1: lane 0 is the element at p
         const bool mine = lane < cnt;
@@ -385,18 +454,27 @@ __global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__res
     constexpr uint32_t kCmGroup = 16;
     __shared__ ChunkMap cm_rows[kCmGroup * 64];  // chunk maps of kCmGroup chunks
     __shared__ uint2 seg_rows[kChunkSegs * 64];  // segment maps of the chunk that is being walked
+    __shared__ __attribute__((aligned(16))) uint8_t far_bytes[kFarChunks * 16];
     const uint32_t kSeg = 1u << seg_shift;
     const uint32_t lane = threadIdx.x;
     const uint32_t n_chunk = (n_seg + kChunkSegs - 1) / kChunkSegs;
     uint32_t p = body, out = 0;
+    uint32_t run_size = 0;  // size of the elements of the last run of equal-sized elements (0: none yet)
     bool ok = true;
+    RES_CLOCK(tk0);
     for (uint32_t c = 0; c < n_chunk && ok; c++) {
         if (c % kCmGroup == 0) {
             __syncthreads();  // (the rows of the group before have been read)
-            const uint32_t cnt = n_chunk - c < kCmGroup ? n_chunk - c : kCmGroup;
-#pragma unroll 16
-            for (uint32_t i = 0; i < cnt; i++)
-                cm_rows[i * 64 + lane] = cmaps[(size_t)(c + i) * 64 + lane];
+            // (all rows requested before the first one is stored: rows past the last chunk repeat it, unread)
+            ChunkMap row[kCmGroup];
+#pragma unroll
+            for (uint32_t i = 0; i < kCmGroup; i++) {
+                const uint32_t ci = c + i < n_chunk ? c + i : n_chunk - 1;
+                row[i] = cmaps[(size_t)ci * 64 + lane];
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kCmGroup; i++)
+                cm_rows[i * 64 + lane] = row[i];
             __syncthreads();
         }
         const uint64_t cb64 = (uint64_t)c * kChunkSegs * kSeg;
@@ -414,15 +492,32 @@ __global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__res
                     regular = true;
                 }
             }
+            RES_COUNT(regular ? 4 : 5, 1);
             if (!regular) {
                 const uint32_t s0 = c * kChunkSegs, cnt = n_seg - s0 < kChunkSegs ? n_seg - s0 : kChunkSegs;
-                ok = walk_segments(in, n, seg_shift, maps, chk, entries, p, out, chunk_end, lane, seg_rows, s0, cnt);
+                RES_CLOCK(tw0);
+                ok = walk_segments(in, n, seg_shift, maps, chk, entries, p, out, chunk_end, lane, seg_rows, s0, cnt, far_bytes, run_size);
+#ifdef SZ_STREAM_DEBUG
+                RES_CLOCK(tw1);
+                RES_COUNT(6, tw1 - tw0);
+#endif
             }
         }
         if (lane == 0)
             centries[c] = ce;
     }
     ok = ok && p == n && out == ulen;
+#ifdef SZ_STREAM_DEBUG
+    {
+        RES_CLOCK(tk1);
+        if (lane == 0) {
+            printf("serial pass: %llu clocks; chunks through their map %llu, walked %llu (%llu clocks); in walked chunks: segment maps "
+                   "%llu, entries far from a segment's start %llu (%llu windows, %llu clocks), runs of equal elements %llu; rows into LDS %llu clocks\n",
+                   tk1 - tk0, g_res_dbg[4], g_res_dbg[5], g_res_dbg[6], g_res_dbg[0], g_res_dbg[1], g_res_dbg[2], g_res_dbg[8], g_res_dbg[3], g_res_dbg[7]);
+            for (int i = 0; i < 16; i++) g_res_dbg[i] = 0;
+        }
+    }
+#endif
     if (lane == 0)
         result[0] = ok ? 0u : 1u;
 }
