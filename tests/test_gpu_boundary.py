@@ -724,6 +724,57 @@ def test_device_stream_decode_without_side_information():
     assert st[0] == 0 and st[1] != 0
 
 
+def test_streams_of_big_elements_go_through_the_runs_pass():
+    """Pass 0 of the stream index (one wave following runs of equal-sized big elements) covers a stream whose
+    fragments are one literal each; a stream it cannot cover falls to the segment passes.  Either way the decode
+    equals the input, and damage is reported or decoded exactly as the oracle decodes it."""
+    import torch
+    P = pkg()
+    rs = np.random.RandomState(99)
+    noise = rs.randint(0, 256, size=65536 * 300 + 12345, dtype=np.uint8).tobytes()
+    mtg = fuzzgen.corpus("mtg")
+
+    def run(c, ulen, body):
+        buf = torch.zeros(len(c) + 64, dtype=torch.uint8, device="cuda")
+        buf[:len(c)] = torch.from_numpy(np.frombuffer(c, dtype=np.uint8).copy()).cuda()
+        out, st = P.uncompress_stream(buf, len(c), body, ulen)
+        torch.cuda.synchronize()
+        return out.cpu().numpy().tobytes(), st.cpu().numpy().tolist()
+
+    def body_of(c):
+        b = 1
+        while c[b - 1] & 0x80:
+            b += 1
+        return b
+
+    mixed = noise[:65536 * 150] + mtg[:65536 * 2] + noise[65536 * 150:]
+    for data in (noise, noise[:65536 * 257], mixed, noise[:65536 + 1]):
+        comp = oracle_lib.raw_compress(data)
+        out, st = run(comp, len(data), body_of(comp))
+        assert st == [0, 0, 0] and out == data
+    comp = oracle_lib.raw_compress(noise)
+    body = body_of(comp)
+    reported = 0
+    for k in range(10):
+        s = bytearray(comp)
+        if k < 5:  # a literal's tag or length bytes (every fragment starts 65 539 bytes after the one before)
+            s[body + 65539 * int(rs.randint(0, 300)) + int(rs.randint(0, 3))] ^= 1 << int(rs.randint(0, 8))
+        else:
+            s[int(rs.randint(body, len(s)))] ^= 1 << int(rs.randint(0, 8))
+        out, st = run(bytes(s), len(noise), body)
+        try:
+            want = oracle_lib.uncompress(bytes(s))
+        except ValueError:
+            want = None
+        if st == [0, 0, 0]:
+            assert want is not None and out == want
+        else:
+            reported += 1
+    assert reported >= 3
+    out, st = run(comp[:len(comp) - 70000], len(noise), body)  # truncated
+    assert st != [0, 0, 0]
+
+
 def test_two_host_threads_launching_on_the_same_stream():
     """The multi-wave kernel's workspace (sample counters, block queue) belongs to (device, stream): two
     host threads that launch on the SAME stream -- here the NULL stream, the default of the binding --

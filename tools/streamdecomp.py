@@ -10,9 +10,12 @@ import fuzzgen
 from pkg_loader import load_package
 P = load_package()
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for name, corpus in (("text", fuzzgen.corpus("mtg")), ("random", fuzzgen.corpus("random_ascii"))):
+for name, corpus in (("text", fuzzgen.corpus("mtg")), ("random", fuzzgen.corpus("random_ascii")), ("noise", None)):
     total = mib << 20
-    data = (corpus * (total // len(corpus) + 1))[:total]
+    if corpus is None:  # every fragment one literal: the index's pass 0 covers the stream
+        data = np.random.default_rng(7).integers(0, 256, total, dtype=np.uint8).tobytes()
+    else:
+        data = (corpus * (total // len(corpus) + 1))[:total]
     comp = P.compress(data)
     n = len(comp)
     body = 1

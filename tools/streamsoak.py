@@ -29,6 +29,9 @@ def body_of(data):
 
 def piece():
     parts = []
+    if rs.rand() < 0.02:  # now and then a stream of several index chunks (64 segments of 16 KiB each)
+        k = kinds[int(rs.randint(len(kinds)))]
+        return fuzzgen.gen(k, int(rs.randint(1 << 30)), int(rs.randint(40, 200)) * 65536 + int(rs.randint(0, 65536))).tobytes()
     for _ in range(int(rs.randint(1, 6))):
         k = kinds[int(rs.randint(len(kinds)))]
         parts.append(fuzzgen.gen(k, int(rs.randint(1 << 30)), int(rs.randint(1, 5)) * 65536 if rs.rand() < 0.5 else int(rs.randint(1000, 300000))).tobytes())
