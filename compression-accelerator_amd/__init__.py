@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "sz_uncompress_blocks_hip", "sz_uncompress_packed_hip", "sz_uncompress_stream_work_bytes",
     "sz_uncompress_stream_hip", "sz_compress", "sz_uncompress", "sz_get_uncompressed_length",
     "sz_rocc_cmd", "rocc_cmd", "sz_rocc_last_error", "sz_release_thread_resources",
-    "sz_release_stream_resources", "sz_device_count",
+    "sz_release_stream_resources", "sz_shard_range", "sz_stream_offsets", "sz_device_count",
     "sz_last_hip_error", "sz_strerror", "sz_version",
 )
 
@@ -94,6 +94,10 @@ def lib():
     L.sz_release_thread_resources.restype = None
     L.sz_release_stream_resources.argtypes = [vp]
     L.sz_release_stream_resources.restype = i32
+    L.sz_shard_range.argtypes = [u64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.sz_shard_range.restype = i32
+    L.sz_stream_offsets.argtypes = [vp, u64, u64, u64, vp, ctypes.POINTER(u64)]
+    L.sz_stream_offsets.restype = i32
     L.sz_device_count.restype = i32
     L.sz_last_hip_error.restype = i32
     L.sz_strerror.argtypes = [i32]

@@ -232,6 +232,36 @@ extern "C" {
 
 size_t sz_max_compressed_length(size_t n) { return 32 + n + n / 6; }
 
+int sz_shard_range(uint64_t n_blocks_total, uint32_t rank, uint32_t world, uint64_t *begin, uint64_t *end)
+{
+    if (world == 0 || rank >= world || !begin || !end)
+        return SZ_EINVAL;
+    const uint64_t base = n_blocks_total / world, rem = n_blocks_total % world;
+    const uint64_t b = (uint64_t)rank * base + (rank < rem ? rank : rem);
+    *begin = b;
+    *end = b + base + (rank < rem ? 1u : 0u);
+    return SZ_OK;
+}
+
+int sz_stream_offsets(const uint32_t *lens, uint64_t n_blocks, uint64_t base, uint64_t slot_stride,
+                      uint64_t *offsets, uint64_t *bad_block)
+{
+    if (!offsets || (n_blocks && !lens))
+        return SZ_EINVAL;
+    uint64_t o = base;
+    for (uint64_t i = 0; i < n_blocks; i++) {
+        offsets[i] = o;
+        if (lens[i] >= 0xfffffffdu || (slot_stride && lens[i] > slot_stride)) {
+            if (bad_block)
+                *bad_block = i;
+            return SZ_ECORRUPT;
+        }
+        o += lens[i];
+    }
+    offsets[n_blocks] = o;
+    return SZ_OK;
+}
+
 int sz_device_count(void)
 {
     int n = 0;

@@ -167,6 +167,22 @@ int sz_rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2, uint64_t *rd
 uint64_t rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2);
 int sz_rocc_last_error(void);
 
+/* ---- multi-GPU (the Python side of the same two steps: sharding.py) -------
+ * The path shards by contiguous ranges of independent 64 KiB blocks, one process per GPU, no data-path
+ * collective: every rank selects its device (hipSetDevice -- the entry points above follow the calling
+ * thread's current device), compresses blocks [begin, end) of the job into its own slots, and the ranks
+ * exchange nothing but the per-block lengths (one all-gather of uint32, RCCL: ncclAllGather).  Both
+ * helpers are host arithmetic and need no GPU. */
+/* The balanced contiguous range of rank `rank` of `world` (the first n_blocks_total % world ranks get one
+ * block more).  SZ_EINVAL if world == 0, rank >= world or a pointer is null. */
+int sz_shard_range(uint64_t n_blocks_total, uint32_t rank, uint32_t world, uint64_t *begin, uint64_t *end);
+/* Layout of the whole packed stream from the gathered lengths: offsets[i] = base + lens[0] + ... + lens[i-1]
+ * for i = 0 .. n_blocks (base = bytes of the stream's preamble).  SZ_ECORRUPT, and *bad_block set if not
+ * null, if a length is one of the kernels' markers (>= 0xfffffffd: the block was not compressed) or
+ * exceeds `slot_stride`. */
+int sz_stream_offsets(const uint32_t *lens, uint64_t n_blocks, uint64_t base, uint64_t slot_stride,
+                      uint64_t *offsets, uint64_t *bad_block);
+
 /* ---- misc ------------------------------------------------------------------------------- */
 /* Frees the calling thread's cached device workspace (its stream, five buffers and the 64 MiB below),
  * used by the host-buffer API and the RoCC surface.  It is NOT freed when the thread exits (the HIP

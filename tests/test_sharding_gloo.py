@@ -70,6 +70,38 @@ def test_two_rank_length_gather_matches_single_process(n_total):
         assert offs == want_off, rank
 
 
+def test_c_abi_sharding_helpers_agree_with_the_python_side():
+    """sz_shard_range / sz_stream_offsets (include/snappy_hip.h, host arithmetic: no GPU): what a C, JNI or cgo host
+    uses for the two steps sharding.py does in Python -- the same ranges, the same layout, the same refusals."""
+    import ctypes
+    from pkg_loader import load_package
+    P = load_package()
+    from compression_accelerator_amd import sharding
+    L = P.lib()
+    u64 = ctypes.c_uint64
+    for n in (0, 1, 7, 8, 9, 65, 16386, 262144):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                b, e = u64(), u64()
+                assert L.sz_shard_range(n, rank, world, ctypes.byref(b), ctypes.byref(e)) == 0
+                assert (b.value, e.value) == sharding.shard_range(n, rank, world)
+    b, e = u64(), u64()
+    assert L.sz_shard_range(10, 2, 2, ctypes.byref(b), ctypes.byref(e)) == P.SZ_EINVAL
+    assert L.sz_shard_range(10, 0, 0, ctypes.byref(b), ctypes.byref(e)) == P.SZ_EINVAL
+    rs = np.random.RandomState(5)
+    lens = rs.randint(1, 76490, size=1000).astype(np.uint32)
+    offs = np.zeros(1001, dtype=np.uint64)
+    bad = u64(12345)
+    assert L.sz_stream_offsets(lens.ctypes.data, 1000, 5, 76544, offs.ctypes.data, ctypes.byref(bad)) == 0
+    assert offs[0] == 5 and (np.diff(offs.astype(np.int64)) == lens).all()
+    for marker in (0xffffffff, 0xfffffffe, 0xfffffffd, 76545):
+        l2 = lens.copy()
+        l2[321] = marker
+        assert L.sz_stream_offsets(l2.ctypes.data, 1000, 5, 76544, offs.ctypes.data, ctypes.byref(bad)) == P.SZ_ECORRUPT
+        assert bad.value == 321
+    assert L.sz_stream_offsets(None, 0, 3, 76544, offs.ctypes.data, None) == 0 and offs[0] == 3
+
+
 def test_shard_range_partitions_exactly():
     load_package()
     from compression_accelerator_amd import sharding
