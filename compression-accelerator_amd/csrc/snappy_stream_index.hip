@@ -228,6 +228,155 @@ __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *
     maps[(size_t)s * 64 + lane] = make_uint2(pos, out);
 }
 
+// ---- 1b. entries FAR from a segment's start
+// A parse enters a segment more than 63 bytes behind its start when an element (a literal of hundreds of bytes or
+// more) reaches that far into it: no map covers such an entry.  From there the parse is followed with 64-byte
+// windows (2 KiB of the stream at a time in LDS: one trip to memory, not one per window) until it stands on a
+// checkpoint of the segment -- then that hypothesis' exit is its exit -- or leaves the segment.
+// p, out: the parse (wave-uniform); false: a malformed element.  map_of(rel) = the segment's map entry.
+static constexpr uint32_t kFarChunks = 128;  // 16-byte pieces of the stream kept in LDS while windows are walked
+template <typename MapFn>
+__device__ __forceinline__ bool follow_far_entry(const uint8_t *__restrict__ in, uint32_t n, uint32_t seg_base,
+                                                 uint32_t seg_end, uint32_t n_chk, const uint2 *__restrict__ seg_chk,
+                                                 MapFn map_of, uint8_t *far_bytes, uint32_t &p, uint32_t &out,
+                                                 uint32_t lane)
+{
+    // the segment's checkpoints, one per lane (n_chk <= 64): the parse has met a hypothesis of pass 1 when one of
+    // them is an element start of its own (a checkpoint is AN element start of its hypothesis shortly behind its mark,
+    // not the first one behind it: comparing only the first element behind a mark can miss for KiB after KiB)
+    (void)seg_base;
+    const uint2 kc = lane < n_chk ? seg_chk[lane] : make_uint2(kBad, 0);
+    uint32_t b0 = kBad, bend = 0;  // far_bytes holds stream bytes [b0, bend)
+    while (p < seg_end) {
+        if (!(p >= b0 && p + 72u <= bend) && n + 8u - p >= 72u) {  // (the caller's buffer is readable to n + 8)
+            const uint32_t avail = n + 8u - p;
+            const uint32_t nck = avail / 16u < kFarChunks ? avail / 16u : kFarChunks;
+            __syncthreads();  // (single-wave workgroup: orders the LDS accesses of its lanes)
+#pragma unroll
+            for (uint32_t k = 0; k < kFarChunks; k += 64) {
+                if (k + lane < nck) {
+                    const u32x4 v = ld128(in + p + 16u * (k + lane));
+                    __builtin_memcpy(far_bytes + 16u * (k + lane), &v, 16);
+                }
+            }
+            __syncthreads();
+            b0 = p;
+            bend = p + 16u * nck;
+        }
+        // the elements that start in [p, p + 62] on the chain from p
+        const uint32_t q = p + lane;
+        Elem e;
+        e.size = 0;
+        e.olen = 0;
+        e.ok = true;
+        if (q < n) {
+            uint64_t x;
+            if (p >= b0 && p + 72u <= bend)
+                __builtin_memcpy(&x, far_bytes + (q - b0), 8);
+            else
+                x = ld64(in + q);
+            e = element_of(x, q, n);
+        }
+        const uint32_t end = lane + e.size;
+        const uint32_t nx = (q >= n || !e.ok || end > 62 || lane == 63) ? 63u : end;
+        uint64_t Mm;
+        {
+            uint32_t jump = nx, on = lane == 0 ? 1u : 0u;  // (pointer doubling, as the decoder finds a window's elements)
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+                on |= (uint32_t)__builtin_amdgcn_ds_permute((int)((on ? jump : 63u) << 2), (int)on);
+                jump = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jump << 2), (int)jump);
+            }
+            Mm = ballot64(on != 0 && lane != 63 && q < seg_end);  // only the elements that start inside the segment
+        }
+        if (ballot64(((Mm >> lane) & 1) && !e.ok) != 0)
+            return false;
+        const bool mine = (Mm >> lane) & 1;
+        const uint32_t e_last = 63u - (uint32_t)__builtin_clzll(Mm);  // (lane 0 is always on the chain: Mm != 0)
+        const uint32_t olen = mine ? e.olen : 0u;
+        const uint32_t incl = wave_inclusive_sum(olen);
+        const uint32_t start = out + (incl - olen);
+        {
+            const uint32_t relc = kc.x - p;
+            const uint64_t meet = ballot64(kc.x != kBad && kc.x >= p && relc < 64u && ((Mm >> (relc & 63u)) & 1ull));
+            if (meet) {
+                const uint32_t jj = ctz64(meet);  // the checkpoint's hypothesis: its exit, the bytes it has produced by then and by here
+                const uint32_t cy = lane_get(kc.y, jj);
+                const uint2 m = map_of(cy >> 26);
+                if (uni(m.x) == kBad)
+                    return false;
+                out = lane_get(start, lane_get(relc, jj)) + uni(m.y) - (cy & 0x3ffffffu);
+                p = uni(m.x);
+                return true;
+            }
+        }
+        out += lane_get(incl, 63);
+        p += e_last + lane_get(e.size, e_last);
+    }
+    return true;
+}
+
+// Pass 1b, one wave per segment: WHERE parses can enter a segment far from its start is known from the maps -- the
+// exits of the hypothetical parses of the segments before it, and the true parse's exit is one of them.  Every
+// segment follows the exit that most of its 64 parses share (they fall into step within a few elements: in a
+// compressible stream that is the true parse) into the segment where it lands, if it lands far from that one's
+// start, and leaves (entry, exit, bytes produced, ok) in THAT segment's far map; passes 2a-2c look entries up there
+// instead of leaving them to the one wave of the serial pass (24 windows each, ~1 us a window).  An entry nobody
+// foresaw (a minority's exit, more than kFarSlots entries into one segment) is walked by the serial pass as before.
+static constexpr uint32_t kFarSlots = 4;
+struct FarEntry {
+    uint32_t pos, exit, out, st;  // st: 0 = followed, 1 = malformed element on the way
+};
+__global__ __launch_bounds__(64) void stream_far_maps_kernel(const uint8_t *__restrict__ in, uint32_t n, uint32_t n_seg,
+                                                             uint32_t seg_shift, const uint2 *__restrict__ maps,
+                                                             const uint2 *__restrict__ chk, FarEntry *__restrict__ far,
+                                                             uint32_t *__restrict__ far_cnt,
+                                                             const uint32_t *__restrict__ covered)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t far_bytes[kFarChunks * 16];
+    const uint32_t kSeg = 1u << seg_shift;
+    const uint32_t lane = threadIdx.x, s = blockIdx.x;
+    if (s >= n_seg || *covered)
+        return;
+    const uint32_t q = maps[(size_t)s * 64 + lane].x;  // (an exit lies at or behind this segment's end)
+    const bool far_q = q != kBad && q < n && (q & (kSeg - 1u)) >= 64u;
+    uint64_t todo = ballot64(far_q);
+    uint32_t best = kBad, best_cnt = 0;
+    for (uint32_t i = 0; i < 8 && todo; i++) {  // (the parses have joined into a few packs by the segment's end)
+        const uint32_t q0 = lane_get(q, ctz64(todo));
+        const uint64_t m = ballot64(far_q && q == q0);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+        if (cnt > best_cnt) {
+            best_cnt = cnt;
+            best = q0;
+        }
+        todo &= ~m;
+    }
+    if (best_cnt == 0)
+        return;
+    const uint32_t t = best >> seg_shift;  // the segment the exit lands in (t > s)
+    const uint32_t seg_base = t * kSeg;
+    const uint32_t seg_end = seg_base + kSeg < n ? seg_base + kSeg : n;
+    const uint32_t n_chk = kSeg >> kChkShift;
+    uint32_t p = best, out = 0;
+    const bool ok = follow_far_entry(in, n, seg_base, seg_end, n_chk, chk + (size_t)t * n_chk,
+                                     [&](uint32_t rel) { return maps[(size_t)t * 64 + rel]; }, far_bytes, p, out, lane);
+    uint32_t k = 0;
+    if (lane == 0)
+        k = atomicAdd(far_cnt + t, 1u);
+    k = uni(k);
+    if (k < kFarSlots && lane == 0)
+        far[(size_t)t * kFarSlots + k] = FarEntry{best, p, out, ok ? 0u : 1u};
+}
+// the far map's answer for an entry at `pos` into segment s: slot index, or kFarSlots if it has none
+__device__ __forceinline__ uint32_t far_slot(const FarEntry *__restrict__ far, uint32_t s, uint32_t pos)
+{
+    for (uint32_t k = 0; k < kFarSlots; k++)
+        if (far[(size_t)s * kFarSlots + k].pos == pos)
+            return k;
+    return kFarSlots;
+}
+
 // ---- 2. the true parse through the segments, in three short passes instead of one long serial walk
 // A segment map is a function "entry offset (< 64) -> exit position, bytes produced", and such functions
 // compose.  2a: one wave per CHUNK of 64 segments composes its segments' maps for all 64 entry offsets at
@@ -242,7 +391,6 @@ __global__ __launch_bounds__(64) void stream_segment_maps_kernel(const uint8_t *
 // entries[s] = (position, bytes produced) where the true parse enters segment s, (kBad, 0) where no
 // element starts in the segment; result[0] = 0 if the stream parses cleanly to its end.
 static constexpr uint32_t kChunkSegs = 64;
-static constexpr uint32_t kFarChunks = 128;  // 16-byte pieces of the stream the serial pass keeps in LDS while it walks windows
 static constexpr uint32_t kStRun = 0, kStFar = 1, kStBad = 2;
 
 struct ChunkMap {
@@ -252,6 +400,7 @@ struct ChunkMap {
 __global__ __launch_bounds__(64) void stream_chunk_maps_kernel(uint32_t n, uint32_t n_seg, uint32_t seg_shift,
                                                                const uint2 *__restrict__ maps,
                                                                ChunkMap *__restrict__ cmaps,
+                                                               const FarEntry *__restrict__ far,
                                                                const uint32_t *__restrict__ covered)
 {
     if (*covered)
@@ -273,8 +422,19 @@ __global__ __launch_bounds__(64) void stream_chunk_maps_kernel(uint32_t n, uint3
                     pos = m.x;
                     out += m.y;
                 }
-            } else {
-                st = kStFar;  // far into the segment: no map covers this entry
+            } else {  // far into the segment: pass 1b has followed the entries it could foresee
+                const uint32_t k = far_slot(far, s, pos);
+                if (k == kFarSlots) {
+                    st = kStFar;  // not this one: the serial pass walks this chunk
+                } else {
+                    const FarEntry f = far[(size_t)s * kFarSlots + k];
+                    if (f.st != 0) {
+                        st = kStBad;
+                    } else {
+                        pos = f.exit;
+                        out += f.out;
+                    }
+                }
             }
         }
     }
@@ -298,7 +458,8 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
                                               const uint2 *__restrict__ maps, const uint2 *__restrict__ chk,
                                               uint2 *__restrict__ entries, uint32_t &p, uint32_t &out,
                                               uint32_t until, uint32_t lane, uint2 *rows, uint32_t row_s0,
-                                              uint32_t row_cnt, uint8_t *far_bytes, uint32_t &run_size)
+                                              uint32_t row_cnt, uint8_t *far_bytes, uint32_t &run_size,
+                                              const FarEntry *__restrict__ far)
 {
     const uint32_t kSeg = 1u << seg_shift;
     uint32_t last_seg = kBad;
@@ -357,68 +518,23 @@ __device__ __forceinline__ bool walk_segments(const uint8_t *__restrict__ in, ui
         if (!lane_get(es.ok ? 1u : 0u, 0))
             return false;
         if (size0 < 64) {
-            // small elements (the inside of a compressible fragment): 64-byte window steps until the
-            // parse stands on a checkpoint of the segment's hypothesis 0 -- then that hypothesis' exit is
-            // this parse's exit -- or reaches the end of the segment
+            // small elements (the inside of a compressible fragment): pass 1b's answer if it has one for this
+            // entry, else 64-byte window steps until the parse stands on a checkpoint of the segment
             const uint32_t seg_end = seg_base + kSeg < until ? seg_base + kSeg : until;
             const uint32_t n_chk = kSeg >> kChkShift;
-            uint32_t mark = ((p - seg_base) >> kChkShift) + 1;  // the next KiB mark ahead
-            bool merged = false;
             RES_COUNT(1, 1);
-            RES_CLOCK(tq0);
-            // (every window's bytes would be a dependent trip to memory of this one wave -- ~1 us, two dozen windows
-            // until a checkpoint --: 2 KiB of the stream from p on are brought into LDS in one trip instead)
-            uint32_t b0 = kBad, bend = 0;  // far_bytes holds stream bytes [b0, bend)
-            while (p < seg_end) {
-                uint32_t E, O;
-                RES_COUNT(2, 1);
-                if (!(p >= b0 && p + 72u <= bend) && n + 8u - p >= 72u) {  // (the caller's buffer is readable to n + 8)
-                    const uint32_t avail = n + 8u - p;
-                    const uint32_t nck = avail / 16u < kFarChunks ? avail / 16u : kFarChunks;
-                    __syncthreads();
-#pragma unroll
-                    for (uint32_t k = 0; k < kFarChunks; k += 64) {
-                        if (k + lane < nck) {
-                            const u32x4 v = ld128(in + p + 16u * (k + lane));
-                            __builtin_memcpy(far_bytes + 16u * (k + lane), &v, 16);
-                        }
-                    }
-                    __syncthreads();
-                    b0 = p;
-                    bend = p + 16u * nck;
-                }
-                if (p >= b0 && p + 72u <= bend)
-                    window_map_from(far_bytes + (p - b0), p, seg_end, n, lane, E, O);
-                else
-                    window_map(in, p, seg_end, n, lane, E, O);
-                const uint32_t ex = lane_get(E, 0), os = lane_get(O, 0);
-                if (ex == kBad)
+            const uint32_t fk = seg_end == seg_base + kSeg || seg_end == n ? far_slot(far, s, p) : kFarSlots;
+            if (fk != kFarSlots) {
+                const FarEntry f = far[(size_t)s * kFarSlots + fk];
+                if (uni(f.st) != 0)
                     return false;
-                out += os;
-                p += ex;
-                if (p < seg_end && ((p - seg_base) >> kChkShift) >= mark) {
-                    const uint32_t mk = (p - seg_base) >> kChkShift;
-                    // (this parse's first element at or past mark `mark`; the checkpoint of a later mark it
-                    // may have jumped over is the same element or none of its own)
-                    const uint2 c = chk[(size_t)s * n_chk + mark];
-                    if (uni(c.x) == p) {
-                        // (the checkpoint's hypothesis: its exit and the bytes it has produced by then and by here)
-                        const uint2 m = map_of(s, uni(c.y) >> 26);
-                        if (uni(m.x) == kBad)
-                            return false;
-                        out += uni(m.y) - (uni(c.y) & 0x3ffffffu);
-                        p = uni(m.x);
-                        merged = true;
-                        break;
-                    }
-                    mark = mk + 1;
-                }
+                p = uni(f.exit);
+                out += uni(f.out);
+                continue;
             }
-            (void)merged;
-#ifdef SZ_STREAM_DEBUG
-            RES_CLOCK(tq1);
-            RES_COUNT(8, tq1 - tq0);
-#endif
+            if (!follow_far_entry(in, n, seg_base, seg_end, n_chk, chk + (size_t)s * n_chk,
+                                  [&](uint32_t r) { return map_of(s, r); }, far_bytes, p, out, lane))
+                return false;
             continue;
         }
         RES_COUNT(3, 1);
@@ -452,6 +568,7 @@ __global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__res
                                                             const ChunkMap *__restrict__ cmaps,
                                                             uint2 *__restrict__ entries, uint2 *__restrict__ centries,
                                                             uint32_t *__restrict__ result,
+                                                            const FarEntry *__restrict__ far,
                                                             const uint32_t *__restrict__ covered)
 {
     if (*covered)
@@ -504,7 +621,7 @@ __global__ __launch_bounds__(64) void stream_resolve_kernel(const uint8_t *__res
             if (!regular) {
                 const uint32_t s0 = c * kChunkSegs, cnt = n_seg - s0 < kChunkSegs ? n_seg - s0 : kChunkSegs;
                 RES_CLOCK(tw0);
-                ok = walk_segments(in, n, seg_shift, maps, chk, entries, p, out, chunk_end, lane, seg_rows, s0, cnt, far_bytes, run_size);
+                ok = walk_segments(in, n, seg_shift, maps, chk, entries, p, out, chunk_end, lane, seg_rows, s0, cnt, far_bytes, run_size, far);
 #ifdef SZ_STREAM_DEBUG
                 RES_CLOCK(tw1);
                 RES_COUNT(6, tw1 - tw0);
@@ -535,6 +652,7 @@ __global__ __launch_bounds__(64) void stream_chunk_entries_kernel(uint32_t n, ui
                                                                   const uint2 *__restrict__ maps,
                                                                   const uint2 *__restrict__ centries,
                                                                   uint2 *__restrict__ entries,
+                                                                  const FarEntry *__restrict__ far,
                                                                   const uint32_t *__restrict__ covered)
 {
     if (*covered)
@@ -551,10 +669,19 @@ __global__ __launch_bounds__(64) void stream_chunk_entries_kernel(uint32_t n, ui
         const uint32_t seg_end = seg_base + kSeg < n ? seg_base + kSeg : n;
         if (p >= seg_end)
             continue;  // inside an element: entries[s] stays (kBad, 0)
-        if (p - seg_base >= 64u)
-            return;  // (not reached: pass 2a ran this path through near entries only)
+        if (p < seg_base)
+            return;  // (not reached)
         if (lane == 0)
             entries[s] = make_uint2(p, out);
+        if (p - seg_base >= 64u) {  // a far entry: pass 2a came through the far map here
+            const uint32_t k = far_slot(far, s, p);
+            if (k == kFarSlots)
+                return;  // (not reached: pass 2a ran this very path)
+            const FarEntry f = far[(size_t)s * kFarSlots + k];
+            p = uni(f.exit);
+            out += uni(f.out);
+            continue;
+        }
         const uint2 m = maps[(size_t)s * 64 + (p - seg_base)];  // (near entry, not kBad: pass 2a ran this path)
         p = uni(m.x);
         out += uni(m.y);
@@ -724,9 +851,15 @@ __global__ __launch_bounds__(256) void stream_index_init_kernel(unsigned long lo
                                                                 uint32_t body, uint32_t n, uint2 *__restrict__ entries,
                                                                 uint32_t n_seg, uint32_t *__restrict__ result,
                                                                 uint32_t *__restrict__ covered,
-                                                                uint2 *__restrict__ centries, uint32_t n_chunk)
+                                                                uint2 *__restrict__ centries, uint32_t n_chunk,
+                                                                FarEntry *__restrict__ far, uint32_t *__restrict__ far_cnt)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_seg) {
+        far_cnt[i] = 0;
+        for (uint32_t k = 0; k < kFarSlots; k++)
+            far[(size_t)i * kFarSlots + k] = FarEntry{kBad, kBad, 0, 1};
+    }
     if (i <= n_frag)
         off[i] = i == 0 ? body : (i == n_frag ? n : ~0ull);
     if (i < n_seg)
@@ -833,7 +966,8 @@ size_t stream_index_scratch_bytes(uint64_t n)
     const size_t n_seg = (size_t)((n + seg - 1) / seg);
     const size_t n_chunk = (n_seg + kChunkSegs - 1) / kChunkSegs;
     return n_seg * 64 * sizeof(uint2) + n_seg * sizeof(uint2) + n_chunk * (64 * sizeof(ChunkMap) + sizeof(uint2)) +
-           (size_t)((n + 1023) / 1024 + 64) * sizeof(uint2) + 64;  // maps, entries, chunk maps + entries, checkpoints
+           (size_t)((n + 1023) / 1024 + 64) * sizeof(uint2) +  // maps, entries, chunk maps + entries, checkpoints
+           n_seg * (kFarSlots * sizeof(FarEntry) + sizeof(uint32_t)) + 16 + 64;  // far maps + their counters, pass 0's flag
 }
 
 // d_in: the whole raw stream (n < 2^31 bytes, readable up to n + 8), body = size of its preamble,
@@ -857,13 +991,18 @@ hipError_t launch_stream_index(const void *d_in, uint64_t n, uint32_t body, uint
     ChunkMap *cmaps = reinterpret_cast<ChunkMap *>(entries + n_seg);
     uint2 *centries = reinterpret_cast<uint2 *>(cmaps + (size_t)n_chunk * 64);
     uint2 *chk = centries + n_chunk;  // (1 << seg_shift) / 1 KiB checkpoints per segment
+    // (far maps behind the checkpoints' area as it is sized -- for the smallest segments --, 16-byte aligned)
+    const size_t chk_area = (size_t)((n + 1023) / 1024 + 64) * sizeof(uint2);
+    const size_t far_off = ((reinterpret_cast<uint8_t *>(chk) - static_cast<uint8_t *>(d_scratch)) + chk_area + 15) & ~(size_t)15;
+    FarEntry *far = reinterpret_cast<FarEntry *>(static_cast<uint8_t *>(d_scratch) + far_off);
+    uint32_t *far_cnt = reinterpret_cast<uint32_t *>(far + (size_t)n_seg * kFarSlots);
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     unsigned long long *off = reinterpret_cast<unsigned long long *>(d_off);
     const uint32_t n_init = n_frag + 1 > n_seg ? n_frag + 1 : n_seg;
     // (the last 64 bytes of the scratch area are nobody's: the flag of pass 0 lives there)
     uint32_t *covered = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_scratch) + stream_index_scratch_bytes(n) - 16);
     hipLaunchKernelGGL(stream_index_init_kernel, dim3(n_init / 256 + 1), dim3(256), 0, stream, off, n_frag, body,
-                       (uint32_t)n, entries, n_seg, d_result, covered, centries, n_chunk);
+                       (uint32_t)n, entries, n_seg, d_result, covered, centries, n_chunk, far, far_cnt);
     SZ_DBG_SYNC("stream_index_init_kernel");
 #ifndef SZ_NO_RUNS_PASS
     hipLaunchKernelGGL(stream_runs_kernel, dim3(1), dim3(64), 0, stream, in, (uint32_t)n, body, (uint32_t)ulen, off, covered);
@@ -872,14 +1011,17 @@ hipError_t launch_stream_index(const void *d_in, uint64_t n, uint32_t body, uint
     hipLaunchKernelGGL(stream_segment_maps_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, n_seg, seg_shift, maps,
                        chk, covered);
     SZ_DBG_SYNC("stream_segment_maps_kernel");
+    hipLaunchKernelGGL(stream_far_maps_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, n_seg, seg_shift, maps, chk,
+                       far, far_cnt, covered);
+    SZ_DBG_SYNC("stream_far_maps_kernel");
     hipLaunchKernelGGL(stream_chunk_maps_kernel, dim3(n_chunk), dim3(64), 0, stream, (uint32_t)n, n_seg, seg_shift, maps,
-                       cmaps, covered);
+                       cmaps, far, covered);
     SZ_DBG_SYNC("stream_chunk_maps_kernel");
     hipLaunchKernelGGL(stream_resolve_kernel, dim3(1), dim3(64), 0, stream, in, (uint32_t)n, body, (uint32_t)ulen,
-                       n_seg, seg_shift, maps, chk, cmaps, entries, centries, d_result, covered);
+                       n_seg, seg_shift, maps, chk, cmaps, entries, centries, d_result, far, covered);
     SZ_DBG_SYNC("stream_resolve_kernel");
     hipLaunchKernelGGL(stream_chunk_entries_kernel, dim3(n_chunk), dim3(64), 0, stream, (uint32_t)n, n_seg, seg_shift,
-                       maps, centries, entries, covered);
+                       maps, centries, entries, far, covered);
     SZ_DBG_SYNC("stream_chunk_entries_kernel");
     hipLaunchKernelGGL(stream_boundaries_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, (uint32_t)ulen,
                        n_seg, seg_shift, entries, maps, chk, off, d_result + 1, covered);
