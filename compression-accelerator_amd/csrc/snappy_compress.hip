@@ -58,6 +58,9 @@ static constexpr uint32_t kTraceCap = 16384, kTraceBlocks = 8;
 #define TRACE(id) do { } while (0)
 #endif
 
+#ifdef SZ_EXP_COUNT
+__device__ unsigned long long g_finish[1u << 18];  // (tools/rolecount.hip: s_memtime at which each block was finished)
+#endif
 #ifdef SZ_PROF
 __device__ unsigned long long g_prof[160];  // [128,160): phases of match_length (16 sums, 16 counts), all waves
 #define ML_START() unsigned long long mlt_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mlt_) :: "memory")
@@ -2440,6 +2443,11 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
 #ifdef SZ_EXP_COUNT
             out_len[b] = op | 0x80000000u;  // (tools/rolecount.hip: a block done by a lone wave)
+            {
+                unsigned long long t_;
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");  // (100 MHz, one clock for the whole GPU)
+                g_finish[b & 0x3ffffu] = t_;  // (every lane, same address, same value)
+            }
 #else
             out_len[b] = op;
 #endif
@@ -2477,6 +2485,13 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             tab, src + (uint64_t)b * in_stride, n, dst + (uint64_t)b * dst_stride, flags, lane, team);
         if (op != kTeamNotMine)
             out_len[b] = op;  // (a9) the wave that finished the block; every lane, same address, same value
+#ifdef SZ_EXP_COUNT
+        if (op != kTeamNotMine) {
+            unsigned long long t_;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+            g_finish[b & 0x3ffffu] = t_;
+        }
+#endif
     }
 }
 

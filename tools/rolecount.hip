@@ -1,9 +1,10 @@
 // tools/rolecount.hip -- who compresses how many blocks of a launch of the team kernel: the teams or the lone waves of
 // its workgroups?  (-DSZ_EXP_COUNT build of the kernels: a lone wave's length carries bit 31.)
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSZ_EXP_COUNT -I../include -I../compression-accelerator_amd/csrc rolecount.hip -o rolecount
-// usage: rolecount <raw input file> [n_blocks]
+// usage: rolecount <raw input file> [n_blocks] [mix]
 #include "../compression-accelerator_amd/csrc/snappy_compress.hip"
 #include <stdio.h>
+#include <string.h>
 #include <vector>
 int main(int argc, char **argv)
 {
@@ -16,11 +17,24 @@ int main(int argc, char **argv)
     uint32_t nb = argc > 2 ? atoi(argv[2]) : 16384;
     std::vector<uint8_t> in((size_t)nb * 65536);
     for (size_t i = 0; i < in.size(); i++) in[i] = h[i % L];
+    if (argc > 3 && !strcmp(argv[3], "mix")) {  // every third block a 4 KiB pattern x 16, every third noise
+        unsigned long long x = 88172645463325252ull;
+        for (uint32_t b = 0; b < nb; b++) {
+            uint8_t *p = &in[(size_t)b * 65536];
+            if (b % 3 == 1) for (uint32_t i = 4096; i < 65536; i++) p[i] = p[i - 4096];
+            if (b % 3 == 2) for (uint32_t i = 0; i < 65536; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; p[i] = (uint8_t)(x >> 32); }
+        }
+    }
     uint8_t *d_in, *d_out; uint32_t *d_len;
     if (hipMalloc(&d_in, in.size()) != hipSuccess || hipMalloc(&d_out, (size_t)nb * 76544) != hipSuccess || hipMalloc(&d_len, nb * 4) != hipSuccess) return 2;
     if (hipMemcpy(d_in, in.data(), in.size(), hipMemcpyHostToDevice) != hipSuccess) return 2;
     szk::DualScratch sc{};
     sc.n_slots = 1024; sc.min_blocks = 2; sc.mode = szk::kDualAlways; sc.kernel = szk::kKernelTeam;
+    if (argc > 3 && !strcmp(argv[3], "mix")) {  // as the library launches it: sampled, queue in cost order
+        sc.mode = szk::kDualAuto;
+        sc.queue_cap = szk::kDualQueueEntries;
+        if (hipMalloc(&sc.queue, (size_t)sc.queue_cap * 4 * 2) != hipSuccess) return 2;
+    }
     if (hipMalloc(&sc.tables, (size_t)sc.n_slots * szk::kDualTablesPerGroup * szk::kDualTableBytes) != hipSuccess || hipMalloc(&sc.select, 64) != hipSuccess || hipMemset(sc.select, 0, 64) != hipSuccess) return 2;
     for (int rep = 0; rep < 3; rep++) {
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0);
@@ -34,6 +48,22 @@ int main(int argc, char **argv)
         for (uint32_t b = 0; b < nb; b++) sel[(ol[b] >> 31) ? 12 : 13]++;
         printf("team %d + lone %d waves, nb=%u: %.3f ms %.1f GB/s; blocks by lone waves %u (%.1f %%), by teams %u\n", szk::kTeamWaves, szk::kLoneWaves, nb, ms,
                nb * 65536.0 / ms / 1e6, sel[12], 100.0 * sel[12] / nb, sel[13]);
+        if (rep == 2) {  // when were the blocks finished?  (s_memrealtime, 100 MHz: from the first to the last finish, in tenths of that span)
+            std::vector<unsigned long long> fin(nb);
+            if (hipMemcpyFromSymbol(fin.data(), HIP_SYMBOL(szk::g_finish), (size_t)nb * 8) != hipSuccess) return 2;
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (uint32_t b = 0; b < nb; b++) { if (fin[b] < t0) t0 = fin[b]; if (fin[b] > t1) t1 = fin[b]; }
+            unsigned hist[2][10] = {{0}};
+            for (uint32_t b = 0; b < nb; b++) {
+                int k = (int)((fin[b] - t0) * 10 / (t1 - t0 + 1));
+                hist[(ol[b] >> 31) ? 1 : 0][k]++;
+            }
+            printf("  blocks finished per tenth of the launch, by teams:");
+            for (int k = 0; k < 10; k++) printf(" %u", hist[0][k]);
+            printf("\n  by lone waves:                                   ");
+            for (int k = 0; k < 10; k++) printf(" %u", hist[1][k]);
+            printf("\n  first to last finish: %.3f ms\n", (t1 - t0) / 1e5);
+        }
     }
     return 0;
 }
