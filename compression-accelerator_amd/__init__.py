@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(CSRC, "libsnappy_hip.so")
 BLOCK_SIZE = 65536
 SLOT_STRIDE = 76544
 FLAG_BLOCK_VARINT = 1
+FLAG_HW_COMPAT = 2  # the reference accelerator's own element stream instead of software Snappy's (include/snappy_hip.h)
 
 SZ_OK, SZ_EINVAL, SZ_ENOSPC, SZ_EHIP, SZ_ENODEV, SZ_ECORRUPT = 0, -22, -28, -5, -19, -74
 
@@ -133,7 +134,7 @@ def _stream_handle(stream):
 
 
 def compress_blocks(src, in_stride, n_blocks, in_len=None, dst=None, dst_stride=SLOT_STRIDE, out_len=None,
-                    varint=True, stream=None):
+                    varint=True, stream=None, hw_compat=False):
     """src: uint8 CUDA tensor holding n_blocks blocks of in_stride bytes (in_len: optional uint32 CUDA
     tensor of per-block lengths).  Returns (dst uint8[n_blocks*dst_stride], out_len uint32[n_blocks]);
     asynchronous on `stream` (default: torch's current stream)."""
@@ -144,7 +145,7 @@ def compress_blocks(src, in_stride, n_blocks, in_len=None, dst=None, dst_stride=
     if out_len is None:
         out_len = torch.empty(n_blocks, dtype=torch.int32, device=src.device)
     _check(lib().sz_compress_blocks_hip(_ptr(src), in_stride, _ptr(in_len), n_blocks, _ptr(dst), dst_stride,
-                                        _ptr(out_len), FLAG_BLOCK_VARINT if varint else 0,
+                                        _ptr(out_len), (FLAG_BLOCK_VARINT if varint else 0) | (FLAG_HW_COMPAT if hw_compat else 0),
                                         _stream_handle(stream)), "sz_compress_blocks_hip")
     return dst, out_len
 

@@ -311,7 +311,7 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
 {
     if (n_blocks == 0)
         return SZ_OK;
-    if (!d_src || !d_dst || !d_out_len || (flags & ~SZ_FLAG_BLOCK_VARINT))
+    if (!d_src || !d_dst || !d_out_len || (flags & ~(SZ_FLAG_BLOCK_VARINT | SZ_FLAG_HW_COMPAT)))
         return SZ_EINVAL;
     if (in_stride == 0 || (!d_in_len && in_stride > SZ_BLOCK_SIZE))
         return SZ_EINVAL;
@@ -319,6 +319,11 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
     const size_t longest = in_stride < SZ_BLOCK_SIZE ? in_stride : SZ_BLOCK_SIZE;
     if (dst_stride < sz_max_compressed_length(longest) + 5)
         return SZ_ENOSPC;
+    if (flags & SZ_FLAG_HW_COMPAT) {  // the accelerator's own element stream (its worst case, n + n / 60 + 1, fits the slot too)
+        SZ_HIP(szk::launch_compress_hw_blocks(d_src, in_stride, d_in_len, 0, n_blocks, d_dst, dst_stride, d_out_len,
+                                              flags, static_cast<hipStream_t>(stream)));
+        return SZ_OK;
+    }
 #ifdef SZ_ABLATION  // diagnostic builds only: timing ablations that produce wrong output
     if (const char *dbg = getenv("SZ_DEBUG_FLAGS"))
         flags |= (uint32_t)strtoul(dbg, nullptr, 0) & 0xff00u;

@@ -37,6 +37,12 @@ hipError_t launch_compress_blocks(const void *d_src, uint64_t in_stride, const u
                                   uint32_t *d_out_len, uint32_t flags, const DualScratch *dual,
                                   hipStream_t stream);
 
+// SZ_FLAG_HW_COMPAT (snappy_hwcompat.hip): the element stream of the reference accelerator's own datapath, one wave per job
+constexpr uint32_t kFlagHwCompat = 2u;  // == SZ_FLAG_HW_COMPAT
+hipError_t launch_compress_hw_blocks(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len, uint64_t total_len,
+                                     uint32_t n_blocks, void *d_dst, uint64_t dst_stride, uint32_t *d_out_len,
+                                     uint32_t flags, hipStream_t stream);
+
 hipError_t launch_compress_stream(const void *d_src, uint64_t n, void *d_slots, uint64_t slot_stride,
                                   uint32_t *d_len, uint32_t flags, const DualScratch *dual, hipStream_t stream);
 

@@ -10,7 +10,7 @@ def pkg():
     return load_package()
 
 
-def compress_many(blocks, varint=True, device="cuda:0"):
+def compress_many(blocks, varint=True, device="cuda:0", hw_compat=False):
     """blocks: list of bytes-like (each <= 64 KiB).  One launch; returns list of bytes."""
     import torch
     P = pkg()
@@ -25,7 +25,7 @@ def compress_many(blocks, varint=True, device="cuda:0"):
     in_len = torch.from_numpy(lens).to(device)
     # poison the output so stale bytes cannot pass for correct ones
     dst = torch.full((nb * P.SLOT_STRIDE,), 0xA5, dtype=torch.uint8, device=device)
-    dst, out_len = P.compress_blocks(src, BLOCK, nb, in_len=in_len, dst=dst, varint=varint)
+    dst, out_len = P.compress_blocks(src, BLOCK, nb, in_len=in_len, dst=dst, varint=varint, hw_compat=hw_compat)
     torch.cuda.synchronize()
     out = dst.cpu().numpy().reshape(nb, P.SLOT_STRIDE)
     ol = out_len.cpu().numpy()
