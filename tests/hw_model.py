@@ -1,5 +1,7 @@
-"""Functional model of the reference ACCELERATOR's own output size ("HW-compatible mode").
-TEST INFRASTRUCTURE -- not a product path, and not the parity target (that is software Snappy, App. C).
+"""Functional model of the reference ACCELERATOR's own output ("HW-compatible mode"): sizes
+(compress_size) and bytes (compress_bytes).  TEST INFRASTRUCTURE: the checker of the library's SZ_FLAG_HW_COMPAT mode
+(csrc/snappy_hwcompat.hip, tests/test_gpu_hwcompat.py) -- never imported by the product; the parity target of
+everything else is software Snappy (App. C).
 
 The RTL cannot be simulated here (no JVM, empty rocket-chip); this is what its datapath does to a buffer, read
 from the Scala as text, at the level of "which bytes become which elements":

@@ -1,6 +1,7 @@
 """the accelerator's own output sizes (benchmark/hw_results.csv) against the functional model
-of its datapath (tests/hw_model.py).  Pins what the model explains and what it does not: a record, not a
-product mode (the reference pins SIZES only for this mode, no bytes)."""
+of its datapath (tests/hw_model.py).  Pins what the model explains and what it does not (the reference pins SIZES
+only for this format, no bytes); the GPU mode that writes this stream (SZ_FLAG_HW_COMPAT) is
+compared with the model in tests/test_gpu_hwcompat.py."""
 import json
 import os
 
