@@ -17,7 +17,8 @@ Headline workload (config.workload): C3 = consecutive 64 KiB windows of the infi
 data/randomASCII.txt (BASELINE.json configs[2], the one the north-star target is quoted on);
 --blocks-per-gpu 32768 (2 GiB per GPU) so that N=8 is config C4's 16 GiB.  Short passes over the
 text (C2-like), low-entropy (C5) and mixed (C4 mix) workloads are reported in "workloads"; "one_stream" is the
-next rows' number (one 1 GiB raw stream compressed + packed, then decoded from its bytes alone).
+next rows' number (one 1 GiB raw stream compressed + packed, then decoded from its bytes alone), "hw_compat" the
+reference accelerator's own format on 4 096 text blocks.
 Every block of every pass is compared with the oracle after the timed region.
 """
 import argparse
@@ -266,6 +267,27 @@ def one_stream(P, kind, n_blocks, device, reps=3):
             "indexed_decode_GBps": round(n / (min(t_d) * 1e-3) / 1e9, 2), "round_trip": ok}
 
 
+def hw_compat_row(P, kind, n_blocks, device, reps=3):
+    """the same blocks in the reference accelerator's own element stream (SZ_FLAG_HW_COMPAT; a
+    compatibility mode, one wave per block) -- rate, ratio, and that the software decoder reads the slots back."""
+    import torch
+    src = make_input(kind, 0, n_blocks, device)
+    dst, ol = P.compress_blocks(src, BLOCK, n_blocks, hw_compat=True)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        P.compress_blocks(src, BLOCK, n_blocks, dst=dst, out_len=ol, hw_compat=True)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    back, _, st = P.uncompress_blocks(dst, P.SLOT_STRIDE, ol, n_blocks)
+    ok = bool(torch.equal(back, src)) and int(st.abs().sum().item()) == 0
+    return {"workload": kind, "blocks": n_blocks, "input_GBps": round(n_blocks * BLOCK / (min(ts) * 1e-3) / 1e9, 2),
+            "compression_ratio": round(n_blocks * BLOCK / float(ol.sum().item()), 4), "decodes_back": ok}
+
+
 def copy_roof(n_bytes, device, reps=10):
     """A plain device-to-device copy of as many bytes as the headline workload reads (torch's copy kernel, the
     same process, the same box, HIP events on the stream it runs on): what this part moves when a kernel
@@ -447,9 +469,10 @@ def rank_main(args):
             if r["layout"] is not None:
                 extras[kind].update(r["layout"])
 
-    stream_row = None
+    stream_row = hw_row = None
     if not args.no_extra and rank == 0 and world == 1:
         stream_row = one_stream(P, "text", 16384, device)
+        hw_row = hw_compat_row(P, "text", 4096, device)
 
     bad_all = main_res["blocks_differing_from_oracle"] + sum(v["blocks_differing_from_oracle"] for v in extras.values())
     if dist_on:
@@ -506,6 +529,7 @@ def rank_main(args):
                                         % (props.name, props.multi_processor_count)},
             "workloads": extras,
             "one_stream": stream_row,
+            "hw_compat": hw_row,
         }
         if main_res["layout"] is not None:
             line.update(main_res["layout"])  # rank 0's view of the all_gather result
