@@ -77,7 +77,7 @@ extern "C" {
                                      reads the slot back -- and larger than Snappy's.  The length the RTL reports
                                      (benchmark/hw_results.csv) is this stream's size + the size of varint32(n) + 1 if
                                      the stream ends with a literal, on 31 of its 36 rows (tests/test_hw_model.py).  One
-                                     wavefront per block, serial parse: a compatibility mode, not a fast path. */
+                                     wavefront per block, 64 positions per step: a compatibility mode, not a fast path. */
 
 /* RoCC command surface constants (tests/compression.c:8-15) */
 #define SZ_ROCC_CHANNEL 3
