@@ -18,7 +18,7 @@ data/randomASCII.txt (BASELINE.json configs[2], the one the north-star target is
 --blocks-per-gpu 32768 (2 GiB per GPU) so that N=8 is config C4's 16 GiB.  Short passes over the
 text (C2-like), low-entropy (C5) and mixed (C4 mix) workloads are reported in "workloads"; "one_stream" is the
 next rows' number (one 1 GiB raw stream compressed + packed, then decoded from its bytes alone), "hw_compat" the
-reference accelerator's own format on 4 096 text blocks.
+reference accelerator's own format on the text workload.
 Every block of every pass is compared with the oracle after the timed region.
 """
 import argparse
@@ -472,7 +472,7 @@ def rank_main(args):
     stream_row = hw_row = None
     if not args.no_extra and rank == 0 and world == 1:
         stream_row = one_stream(P, "text", 16384, device)
-        hw_row = hw_compat_row(P, "text", 4096, device)
+        hw_row = hw_compat_row(P, "text", 16384, device)  # (two rounds of its 8 192 wave slots)
 
     bad_all = main_res["blocks_differing_from_oracle"] + sum(v["blocks_differing_from_oracle"] for v in extras.values())
     if dist_on:
