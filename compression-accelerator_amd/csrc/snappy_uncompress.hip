@@ -78,8 +78,11 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
     // ---- windowed decode: the tags of 64 candidate element starts are decoded at once (lane l looks
     // at compressed byte ip + l), then the elements that really start in the window are walked with
     // v_readlane -- no dependent tag load per element.  Needs ip + 72 <= n; the tail below is serial.
+    uint64_t x_next = 0;     // the next window's bytes, requested as soon as it is known where it begins ...
+    bool have_next = false;  // ... so that the load's latency passes under the rest of this window's work
     while (st == 0 && (uint64_t)ip + 72 <= n && n <= 0x7fffffffu) {  // (32-bit offset sums below)
-        const uint64_t x = ld64(in + ip + lane);
+        const uint64_t x = have_next ? x_next : ld64(in + ip + lane);
+        have_next = false;
         const uint32_t tag = (uint32_t)x & 0xffu;
         const uint32_t extra = (uint32_t)(x >> 8);
         const uint32_t kind_v = tag & 3u;
@@ -145,6 +148,10 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
         } else {  // the last element may reach past the window: the next window starts where it really ends
             const uint32_t e_last = 63u - (uint32_t)__builtin_clzll(Pm);
             j = e_last + lane_get(size_v, e_last);  // (sizes of valid elements fit: n < 2^31)
+        }
+        if ((uint64_t)ip + j + 72 <= n) {
+            x_next = ld64(in + ip + j + lane);
+            have_next = true;
         }
         // ---- output offsets of the window's elements
         const bool is_elem = (Pm >> lane) & 1;
