@@ -183,12 +183,32 @@ __global__ __launch_bounds__(64) void uncompress_streams_kernel(
             const uint32_t mylen = par ? olen : 0u;
             // 16 bytes per step while any element has that many left, then the rest in one step: few
             // predicated memory instructions for the short elements that dominate.
-            uint32_t i = 0;
-            while (__ballot(i + 16 <= mylen) != 0) {
-                if (i + 16 <= mylen) {
-                    const u32x4 v = ld128(sp + i);
-                    __builtin_memcpy(dp + i, &v, 16);
-                    i += 16;
+            // (an element is at most 64 bytes: up to four 16-byte pieces, all requested before the first one is stored
+            // -- one trip to memory for the window, not one per piece)
+            const uint32_t nch = mylen >> 4;
+            const uint32_t i = nch << 4;
+            if (__ballot(nch >= 1) != 0) {
+                u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+                const uint64_t b2 = __ballot(nch >= 2), b3 = __ballot(nch >= 3), b4 = __ballot(nch >= 4);
+                if (nch >= 1) v0 = ld128(sp);
+                if (b2) {
+                    if (nch >= 2) v1 = ld128(sp + 16);
+                    if (b3) {
+                        if (nch >= 3) v2 = ld128(sp + 32);
+                        if (b4) {
+                            if (nch >= 4) v3 = ld128(sp + 48);
+                        }
+                    }
+                }
+                if (nch >= 1) __builtin_memcpy(dp, &v0, 16);
+                if (b2) {
+                    if (nch >= 2) __builtin_memcpy(dp + 16, &v1, 16);
+                    if (b3) {
+                        if (nch >= 3) __builtin_memcpy(dp + 32, &v2, 16);
+                        if (b4) {
+                            if (nch >= 4) __builtin_memcpy(dp + 48, &v3, 16);
+                        }
+                    }
                 }
             }
             // the remaining r = 0..15 bytes, memcpy style: both ends of the rest with one size (the two
