@@ -41,6 +41,9 @@
  *              for compressible launches: three independent waves per workgroup; kept for comparison),
  *              `route` (per block inside the launch: the single kernel hands blocks with a copy to `dual`).
  *              Unset: the sampled choice between `single` and `team`.
+ *   SZ_DECODE_KERNEL  forces a decode kernel: `single` (one wave per stream), `pair` (two:
+ *              one parses the next window while the other moves this one's bytes).  Unset: `pair` for launches
+ *              of up to 4 096 streams, `single` above.  Same output either way.
  *   SZ_SERIAL_UNCOMPRESS=1  makes sz_uncompress skip the parallel fragment index (single-wavefront decode).
  *   SZ_TEST_SEG_SHIFT       a hook of the test-suite (segment size of the fragment index).
  *   SZ_DEBUG_FLAGS          only read by diagnostic builds (-DSZ_ABLATION: timing ablations with wrong output).

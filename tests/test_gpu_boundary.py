@@ -17,6 +17,15 @@ import parity_util
 from gpu_util import compress_many, pkg
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["auto", "single", "pair"], autouse=True)
+def decode_kernel(request, monkeypatch):
+    """Every test of this file through both decode kernels (SZ_DECODE_KERNEL: one wave per stream / parser + mover)
+    and through the library's own choice."""
+    if request.param != "auto":
+        monkeypatch.setenv("SZ_DECODE_KERNEL", request.param)
+    return request.param
 G = fuzzgen.GOLDEN_DIR
 
 
