@@ -28,16 +28,18 @@
 
 namespace szk {
 
-// compressed bytes per segment: 16, 32 or 64 KiB, chosen per stream (small streams want many segments
-// for the parallel passes, large ones few for the serial one)
+// compressed bytes per segment: 4 to 64 KiB, chosen per stream (small streams want many segments for the
+// parallel passes -- a wave walks its segment window by window --, large ones fewer)
 static inline uint32_t seg_shift_for(uint64_t n)
 {
     if (const char *e = getenv("SZ_TEST_SEG_SHIFT")) {  // test hook: every segment size on small streams
         const int v = atoi(e);
-        if (v >= 14 && v <= 16)
+        if (v >= 12 && v <= 16)
             return (uint32_t)v;
     }
-    return n < (64ull << 20) ? 14u : (n < (256ull << 20) ? 15u : 16u);
+    // (measured on text streams after the serial pass stopped caring about the number of segments -- EXPERIMENTS.md
+    // R3.3: 7 MB of stream 0.77 ms at 16 KiB segments, 0.65 at 4 KiB; 232 MB best at 16 KiB; 464 MB at 32 KiB)
+    return n < (24ull << 20) ? 12u : (n < (128ull << 20) ? 13u : (n < (320ull << 20) ? 14u : (n < (1024ull << 20) ? 15u : 16u)));
 }
 static constexpr uint32_t kBad = 0xffffffffu;
 
@@ -962,7 +964,7 @@ __global__ __launch_bounds__(256) void count_failed_kernel(const int32_t *__rest
 // ------------------------------------------------------------------------------- launcher
 size_t stream_index_scratch_bytes(uint64_t n)
 {
-    const uint64_t seg = 1ull << 14;  // sized for the smallest segments (the choice may be overridden in tests)
+    const uint64_t seg = 1ull << seg_shift_for(n);  // (the same choice as the launch makes, test hook included)
     const size_t n_seg = (size_t)((n + seg - 1) / seg);
     const size_t n_chunk = (n_seg + kChunkSegs - 1) / kChunkSegs;
     return n_seg * 64 * sizeof(uint2) + n_seg * sizeof(uint2) + n_chunk * (64 * sizeof(ChunkMap) + sizeof(uint2)) +

@@ -616,14 +616,14 @@ def _literal(payload):
     return bytes([(59 + nb) << 2]) + n.to_bytes(nb, "little") + payload
 
 
-@pytest.mark.parametrize("seg_shift", [None, "15", "16"])
+@pytest.mark.parametrize("seg_shift", [None, "13", "14", "15", "16"])
 def test_large_single_stream_takes_the_indexed_path_and_agrees_with_the_serial_decoder(seg_shift, monkeypatch):
     """sz_uncompress on one stream of many fragments: fragment offsets are found in parallel
     (snappy_stream_index.hip) and the fragments decoded one wave each; streams that are valid but not
     made of 64 KiB fragments, and damaged streams, must come out exactly as from the serial decoder
     (SZ_SERIAL_UNCOMPRESS=1) and the oracle."""
     if seg_shift:
-        monkeypatch.setenv("SZ_TEST_SEG_SHIFT", seg_shift)  # 32 / 64 KiB segments (default here: 16 KiB)
+        monkeypatch.setenv("SZ_TEST_SEG_SHIFT", seg_shift)  # 8 .. 64 KiB segments (default here: 4 KiB)
     P = pkg()
     mtg = fuzzgen.corpus("mtg")
     rs = np.random.RandomState(99)

@@ -39,6 +39,7 @@ def piece():
 
 t0 = time.time(); bad = 0; paths = {"ok": 0, "err": 0}
 for i in range(cases):
+    os.environ["SZ_TEST_SEG_SHIFT"] = str(12 + (i // 5) % 5)  # every segment size of the fragment index in turn
     mode = i % 5
     a = piece()
     if mode == 0:      # intact, fragment-aligned
