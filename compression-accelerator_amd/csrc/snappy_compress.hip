@@ -456,6 +456,9 @@ static constexpr uint32_t kTeamNotMine = 0xfffffffcu; // return value of the wav
 #ifndef SZ_TEAM_PRIO
 #define SZ_TEAM_PRIO 2  // issue priority of the wave that holds the parse token
 #endif
+#ifndef SZ_TEAM_POLL_BACKOFF
+#define SZ_TEAM_POLL_BACKOFF 8  // polls after which a waiting wave polls four times less often (0: never)
+#endif
 
 __device__ __forceinline__ uint64_t team_pack_parse(uint32_t turn, uint32_t P2, uint32_t chain2, uint32_t sc2,
                                                     uint32_t pm1, uint32_t next_emit)
@@ -518,6 +521,14 @@ __device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t tur
             lost = 1;
             break;
         }
+#if SZ_TEAM_POLL_BACKOFF
+        // (a wave that has polled in vain a few times is waiting for something long -- the holder follows a long
+        // match, or runs the general code --: it polls four times less often from then on, its issue slots are the
+        // other waves')
+        if (spin > SZ_TEAM_POLL_BACKOFF)
+            __builtin_amdgcn_s_sleep(4 * SZ_TEAM_POLL_SLEEP);
+        else
+#endif
         __builtin_amdgcn_s_sleep(SZ_TEAM_POLL_SLEEP);
     }
     asm volatile("" ::: "memory");  // nothing of what follows is read before the token
