@@ -456,6 +456,9 @@ static constexpr uint32_t kTeamNotMine = 0xfffffffcu; // return value of the wav
 #ifndef SZ_TEAM_PRIO
 #define SZ_TEAM_PRIO 2  // issue priority of the wave that holds the parse token
 #endif
+#ifndef SZ_TEAM_POLL_BACKOFF_MULT
+#define SZ_TEAM_POLL_BACKOFF_MULT 4
+#endif
 #ifndef SZ_TEAM_POLL_BACKOFF
 #define SZ_TEAM_POLL_BACKOFF 8  // polls after which a waiting wave polls four times less often (0: never)
 #endif
@@ -526,7 +529,7 @@ __device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t tur
         // match, or runs the general code --: it polls four times less often from then on, its issue slots are the
         // other waves')
         if (spin > SZ_TEAM_POLL_BACKOFF)
-            __builtin_amdgcn_s_sleep(4 * SZ_TEAM_POLL_SLEEP);
+            __builtin_amdgcn_s_sleep(SZ_TEAM_POLL_BACKOFF_MULT * SZ_TEAM_POLL_SLEEP);
         else
 #endif
         __builtin_amdgcn_s_sleep(SZ_TEAM_POLL_SLEEP);
