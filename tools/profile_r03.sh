@@ -24,3 +24,8 @@ for k in team dual; do
 done
 timeout -k 10 600 python3 $R/bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 tail -c 600 $O/bench.json
+# stream decode time lines (profiles/r03_stream_kernel_stats.txt: python3 tools/rocpd_kernels.py <db> stream_boundaries <n>)
+timeout -k 10 250 rocprofv3 --kernel-trace --stats -d $O/sd -o sd -- python3 $R/tools/streamdecomp.py 1024 > $O/sd.log 2>&1 || echo "stream stats failed"
+timeout -k 10 250 rocprofv3 --kernel-trace --stats -d $O/sd16 -o sd -- python3 $R/tools/streamdecomp.py 16 > $O/sd16.log 2>&1 || echo "stream 16 stats failed"
+# decoder instruction mix (profiles/r03_decode_pmc.txt)
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/dec -o p -- python3 $R/tools/decompbench.py text 16384 > $O/dec.log 2>&1 || echo "decoder pmc failed"
