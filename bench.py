@@ -18,7 +18,7 @@ data/randomASCII.txt (BASELINE.json configs[2], the one the north-star target is
 --blocks-per-gpu 32768 (2 GiB per GPU) so that N=8 is config C4's 16 GiB.  Short passes over the
 text (C2-like), low-entropy (C5) and mixed (C4 mix) workloads are reported in "workloads"; "one_stream" is the
 next rows' number (one 1 GiB raw stream compressed + packed, then decoded from its bytes alone), "hw_compat" the
-reference accelerator's own format on the text workload.
+functional model of the reference accelerator's datapath on the text workload.
 Every block of every pass is compared with the oracle after the timed region.
 """
 import argparse
@@ -268,8 +268,9 @@ def one_stream(P, kind, n_blocks, device, reps=3):
 
 
 def hw_compat_row(P, kind, n_blocks, device, reps=3):
-    """the same blocks in the reference accelerator's own element stream (SZ_FLAG_HW_COMPAT; a
-    compatibility mode, one wave per block) -- rate, ratio, and that the software decoder reads the slots back."""
+    """the same blocks through SZ_FLAG_HW_COMPAT -- the element stream of a functional model of the
+    reference accelerator's datapath (size-exact on 31 of the 36 rows of benchmark/hw_results.csv, tests/test_hw_model.py;
+    a compatibility mode, one wave per block) -- rate, ratio, and that the software decoder reads the slots back."""
     import torch
     src = make_input(kind, 0, n_blocks, device)
     dst, ol = P.compress_blocks(src, BLOCK, n_blocks, hw_compat=True)
@@ -285,7 +286,8 @@ def hw_compat_row(P, kind, n_blocks, device, reps=3):
     back, _, st = P.uncompress_blocks(dst, P.SLOT_STRIDE, ol, n_blocks)
     ok = bool(torch.equal(back, src)) and int(st.abs().sum().item()) == 0
     return {"workload": kind, "blocks": n_blocks, "input_GBps": round(n_blocks * BLOCK / (min(ts) * 1e-3) / 1e9, 2),
-            "compression_ratio": round(n_blocks * BLOCK / float(ol.sum().item()), 4), "decodes_back": ok}
+            "compression_ratio": round(n_blocks * BLOCK / float(ol.sum().item()), 4), "decodes_back": ok,
+            "what": "functional model of the reference accelerator's datapath (size-exact on 31 of 36 hw_results.csv rows)"}
 
 
 def copy_roof(n_bytes, device, reps=10):

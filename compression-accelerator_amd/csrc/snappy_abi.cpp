@@ -32,21 +32,26 @@ namespace {
 struct DualSlot {
     szk::DualScratch sc{nullptr, nullptr, nullptr, 0, 0, 0, szk::kDualAuto, szk::kKernelTeam};
     std::mutex launch_mu;
+    bool retired = false;  // under launch_mu: the buffers are gone (drop_dual_scratch); a launcher that still holds the slot takes the single kernel
     DualSlot() = default;
     DualSlot(const DualSlot &) = delete;
     DualSlot &operator=(const DualSlot &) = delete;
-    ~DualSlot()
-    {
-        if (sc.tables)
-            (void)hipFree(sc.tables);
-        if (sc.select)
-            (void)hipFree(sc.select);
-        if (sc.queue)
-            (void)hipFree(sc.queue);
-    }
+    // No destructor: device memory is freed on the explicit release path only (drop_dual_scratch), never by
+    // whoever happens to hold the slot last and never at static destruction / dlclose, when the HIP runtime may
+    // already be gone (the same policy as the per-thread workspace below).
 };
-std::mutex g_dual_mutex;
-std::map<std::pair<int, hipStream_t>, std::shared_ptr<DualSlot>> g_dual;
+// The map and its mutex are created on first use and never destroyed, so that no destructor of this library
+// runs HIP calls (or touches the slots) at process exit; workspaces still cached then are left to the driver.
+std::mutex &dual_mutex()
+{
+    static std::mutex *m = new std::mutex;
+    return *m;
+}
+std::map<std::pair<int, hipStream_t>, std::shared_ptr<DualSlot>> &dual_map()
+{
+    static auto *m = new std::map<std::pair<int, hipStream_t>, std::shared_ptr<DualSlot>>;
+    return *m;
+}
 
 int kernel_mode()
 {
@@ -64,8 +69,9 @@ int kernel_mode()
 // single kernel is to run (mode, too few blocks, no memory, stream being captured before a first use).
 // `view` receives the launch parameters for this call.
 // (The slot is returned as a shared_ptr: a concurrent sz_release_stream_resources / Workspace::release of the
-// same stream removes it from the map but cannot destroy it -- nor free its buffers, see drop_dual_scratch --
-// while a launcher still holds it.)  Launches that the small-block kernel takes never use the workspace.
+// same stream removes it from the map and frees its buffers under launch_mu; a launcher that still holds the
+// slot sees `retired` once it has the lock -- lock_live_slot -- and never enqueues on freed memory.)  Launches
+// that the small-block kernel takes never use the workspace.
 std::shared_ptr<DualSlot> dual_slot_for(hipStream_t stream, uint32_t n_blocks, size_t in_stride, const uint32_t *d_in_len,
                                         szk::DualScratch *view)
 {
@@ -77,7 +83,8 @@ std::shared_ptr<DualSlot> dual_slot_for(hipStream_t stream, uint32_t n_blocks, s
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess)
         return nullptr;
-    std::lock_guard<std::mutex> lock(g_dual_mutex);
+    std::lock_guard<std::mutex> lock(dual_mutex());
+    auto &g_dual = dual_map();
     auto key = std::make_pair(dev, stream);
     auto it = g_dual.find(key);
     if (it == g_dual.end()) {
@@ -131,16 +138,43 @@ void drop_dual_scratch(int dev, hipStream_t stream)
 {
     std::shared_ptr<DualSlot> slot;
     {
-        std::lock_guard<std::mutex> lock(g_dual_mutex);
+        std::lock_guard<std::mutex> lock(dual_mutex());
+        auto &g_dual = dual_map();
         auto it = g_dual.find(std::make_pair(dev, stream));
         if (it == g_dual.end())
             return;
         slot = std::move(it->second);
         g_dual.erase(it);
     }
-    // The buffers go when the last holder lets go of the slot (a launcher that looked it up a moment ago may be
-    // about to lock launch_mu and enqueue on them): the destructor of the slot frees them.
-    std::lock_guard<std::mutex> launch(slot->launch_mu);  // (no launch sequence is half enqueued)
+    // Freed here, by the caller that releases the stream's resources (it has synchronised the stream), under
+    // launch_mu: no launch sequence is half enqueued, and a launcher that looked the slot up a moment ago finds
+    // it retired once it holds the lock and runs the single kernel instead (lock_live_slot).
+    std::lock_guard<std::mutex> launch(slot->launch_mu);
+    slot->retired = true;
+    if (slot->sc.tables)
+        (void)hipFree(slot->sc.tables);
+    if (slot->sc.select)
+        (void)hipFree(slot->sc.select);
+    if (slot->sc.queue)
+        (void)hipFree(slot->sc.queue);
+    slot->sc.tables = nullptr;
+    slot->sc.select = nullptr;
+    slot->sc.queue = nullptr;
+}
+
+// Takes the launch lock of a looked-up slot; a slot retired in between is let go (single kernel this time).
+std::unique_lock<std::mutex> lock_live_slot(std::shared_ptr<DualSlot> &slot)
+{
+    std::unique_lock<std::mutex> seq;
+    if (slot) {
+        seq = std::unique_lock<std::mutex>(slot->launch_mu);
+        if (slot->retired) {
+            seq.unlock();
+            seq = std::unique_lock<std::mutex>();
+            slot.reset();
+        }
+    }
+    return seq;
 }
 
 thread_local int tl_hip_error = 0;
@@ -330,9 +364,7 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
 #endif
     szk::DualScratch view;
     std::shared_ptr<DualSlot> slot = dual_slot_for(static_cast<hipStream_t>(stream), n_blocks, in_stride, d_in_len, &view);
-    std::unique_lock<std::mutex> seq;  // one launch sequence at a time per workspace
-    if (slot)
-        seq = std::unique_lock<std::mutex>(slot->launch_mu);
+    std::unique_lock<std::mutex> seq = lock_live_slot(slot);  // one launch sequence at a time per workspace
     SZ_HIP(szk::launch_compress_blocks(d_src, in_stride, d_in_len, n_blocks, d_dst, dst_stride, d_out_len,
                                        flags, slot ? &view : nullptr, static_cast<hipStream_t>(stream)));
     return SZ_OK;
@@ -351,9 +383,7 @@ int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t sl
     const uint32_t n_blocks = (uint32_t)((n + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
     szk::DualScratch view;
     std::shared_ptr<DualSlot> slot = dual_slot_for(static_cast<hipStream_t>(stream), n_blocks, SZ_BLOCK_SIZE, nullptr, &view);
-    std::unique_lock<std::mutex> seq;  // one launch sequence at a time per workspace
-    if (slot)
-        seq = std::unique_lock<std::mutex>(slot->launch_mu);
+    std::unique_lock<std::mutex> seq = lock_live_slot(slot);  // one launch sequence at a time per workspace
     SZ_HIP(szk::launch_compress_stream(d_src, n, d_slots, slot_stride, d_len, flags, slot ? &view : nullptr,
                                        static_cast<hipStream_t>(stream)));
     return SZ_OK;

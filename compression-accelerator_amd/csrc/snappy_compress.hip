@@ -441,9 +441,11 @@ struct WaveTeam {
     unsigned long long *trace;  // (-DSZ_TRACE builds: this wave's stamps for this block, or null)
     uint8_t *scr;    // LDS: 256 bytes of scratch of this wave's own (lanes that share a bucket inside a tile)
     uint32_t *bar;   // LDS: arrivals at the team's barrier (the workgroup may hold waves that are not of the team)
+    const uint32_t *dead;  // LDS: non-zero once a wave of the team has given up (every wave then leaves)
 };
 static constexpr uint32_t kTeamDoneTurn = 0x3fffffu;  // turn field of a token: the block is finished
 static constexpr uint32_t kTeamNotMine = 0xfffffffcu; // return value of the waves that did not finish the block
+static constexpr uint32_t kTeamLost = 0xfffffffbu;    // return value of a wave that gave up waiting for its team (never stored: the kernel poisons the block)
 #ifndef SZ_TEAM_SPIN_CAP
 #define SZ_TEAM_SPIN_CAP (1u << 24)  // polls before a waiting wave gives the block up (seconds: only a lost wave gets there)
 #endif
@@ -484,7 +486,7 @@ __device__ __forceinline__ void team_publish(uint64_t *slot, uint64_t v)
 // until the count has passed the multiple of kWaves its own arrival belongs to.  LDS accesses of a wave made
 // before its arrival are complete before it (the wait), those of the others are visible after it.
 template <int W>
-__device__ __forceinline__ void team_barrier(uint32_t *bar, uint32_t lane)
+__device__ __forceinline__ uint32_t team_barrier(uint32_t *bar, const uint32_t *dead, uint32_t lane)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     uint32_t mine = 0;
@@ -492,13 +494,19 @@ __device__ __forceinline__ void team_barrier(uint32_t *bar, uint32_t lane)
         mine = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     mine = uni(mine);
     const uint32_t target = (mine / W + 1u) * W;
+    uint32_t lost = 1;  // the cap reached, or the team given up by another wave: the caller leaves the persistent loop
     for (uint32_t spin = 0; spin < SZ_TEAM_SPIN_CAP; spin++) {
         const uint32_t now = uni(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if ((int32_t)(now - target) >= 0)
+        if ((int32_t)(now - target) >= 0) {
+            lost = 0;
+            break;
+        }
+        if (uni(__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0)
             break;
         __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
+    return lost;
 }
 
 // waits until the token in `slot` carries `turn` (or "done"); returns the token; lost = 1: gave up
@@ -700,7 +708,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 const uint32_t nvec = (1u << log2T) >> 3;
                 for (uint32_t i = team.wave * 64u + lane; i < nvec; i += 64u * kTeamW)
                     reinterpret_cast<u32x4 *>(tab.lds)[i] = u32x4{0, 0, 0, 0};
-                team_barrier<kTeamW>(team.bar, lane);
+                if (__builtin_expect(team_barrier<kTeamW>(team.bar, team.dead, lane) != 0, 0))
+                    return kTeamLost;  // (the table is not known to be clear: the kernel poisons the block)
             } else {
                 tab.clear(log2T, lane);
             }
@@ -2023,7 +2032,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         PROF_FLUSH();
         if constexpr (kTeamW > 1) {
             if (team_gone)  // another wave finishes (or finished) the block; a lost wave says so
-                return team_lost ? 0xfffffffeu : kTeamNotMine;
+                return team_lost ? kTeamLost : kTeamNotMine;
         }
         if (next_emit < n) {  // remainder literal
             emit_lit(next_emit, n - next_emit);
@@ -2412,7 +2421,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
     __shared__ __attribute__((aligned(16))) uint64_t tokens[2];
     __shared__ __attribute__((aligned(16))) uint8_t dup_scr[kTeamWaves * 256];
     __shared__ uint32_t lone_bm[(kLoneWaves > 0 ? kLoneWaves : 1) * 512];  // one 16384-bit bitmap per global-table wave
-    __shared__ uint32_t next_block, team_bar;
+    __shared__ uint32_t next_block, team_bar, team_dead, len_claim;
     if ((auto_mode & 1u) && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
         return;
     if ((auto_mode & 2u) && (auto_mode & 1u) && !launch_is_mixed(select))
@@ -2432,8 +2441,11 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
         }
         return uni(b0);
     };
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         __hip_atomic_store(&team_bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&team_dead, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&len_claim, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     __syncthreads();  // (the only workgroup-wide barrier: before the waves part ways)
     if (kLoneWaves > 0 && wave >= kTeamWaves) {
         // ---- a lone wave: blocks of its own, table in global memory (as the multi-wave kernel's extra waves)
@@ -2469,27 +2481,46 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
         return;
     }
     const HashTab<true> tab{lds_tab, nullptr, nullptr};
-    WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr, dup_scr + wave * 256u, &team_bar};
+    WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr, dup_scr + wave * 256u, &team_bar, &team_dead};
     __builtin_amdgcn_s_setprio(SZ_TEAM_BASE_PRIO);  // (a team's waves go before the lone ones; the token's holder before both)
+    // Giving up (a wave of the team stalled for seconds: SZ_TEAM_SPIN_CAP): the wave that gives up raises
+    // `team_dead` and every wave of the team leaves the persistent loop at its next look at it -- the barrier's
+    // arrival count is not trusted again.  The block in hand is poisoned (0xfffffffe).  out_len[b] has ONE writer
+    // per block: the first wave to claim `len_claim` (the finisher with the length, or a wave that gave up with
+    // the poison); the blocks this team has not taken stay in the grid's queue for the other workgroups.
     for (;;) {
+        if (uni(__hip_atomic_load(&team_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0)
+            break;
         if (wave == 0) {
             const uint32_t b0 = next_index();
             __hip_atomic_store(&next_block, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        team_barrier<kTeamWaves>(&team_bar, lane);  // every wave of the team is past the block before (it left on the "done" token)
+        uint32_t lost = team_barrier<kTeamWaves>(&team_bar, &team_dead, lane);  // every wave of the team is past the block before (it left on the "done" token)
         uint32_t b = uni(__hip_atomic_load(&next_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (wave == 0) {  // only now: a wave still polling for "done" must not find an empty token instead
+        if (wave == 0 && lost == 0) {  // only now: a wave still polling for "done" must not find an empty token instead
             __hip_atomic_store(&tokens[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&tokens[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&len_claim, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        team_barrier<kTeamWaves>(&team_bar, lane);  // (everyone has the index and sees fresh tokens before any wave goes on)
+        if (lost == 0)
+            lost = team_barrier<kTeamWaves>(&team_bar, &team_dead, lane);  // (everyone has the index and sees fresh tokens before any wave goes on)
+        if (__builtin_expect(lost != 0, 0)) {
+            __hip_atomic_store(&team_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wave == 0 && b < n_work) {  // (wave 0 took this index out of the queue: nobody else will report on it)
+                if (queue)
+                    b = uni(queue[b]);
+                out_len[b] = 0xfffffffeu;
+            }
+            break;
+        }
         if (b >= n_work)
             break;
         if (queue)
             b = uni(queue[b]);
         const uint32_t n = block_length(in_len, total_len, in_stride, b);
         if (n > kMaxBlock) {
-            out_len[b] = 0xffffffffu;
+            if (wave == 0)
+                out_len[b] = 0xffffffffu;
             continue;
         }
 #ifdef SZ_TRACE
@@ -2497,10 +2528,21 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
 #endif
         const uint32_t op = compress_one_block<0, true, HashTab<true>, false, true, SZ_MATCH_PIECES, WaveTeam<kTeamWaves>>(
             tab, src + (uint64_t)b * in_stride, n, dst + (uint64_t)b * dst_stride, flags, lane, team);
-        if (op != kTeamNotMine)
-            out_len[b] = op;  // (a9) the wave that finished the block; every lane, same address, same value
-#ifdef SZ_EXP_COUNT
         if (op != kTeamNotMine) {
+            // (a9) the wave that finished the block, or the first wave that gave it up: every lane, same address, same value
+            uint32_t first = 0;
+            if (lane == 0)
+                first = __hip_atomic_exchange(&len_claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            first = uni(first);
+            if (op == kTeamLost)
+                __hip_atomic_store(&team_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (first == 0)
+                out_len[b] = op == kTeamLost ? 0xfffffffeu : op;
+            if (op == kTeamLost)
+                break;
+        }
+#ifdef SZ_EXP_COUNT
+        if (op != kTeamNotMine && op != kTeamLost) {
             unsigned long long t_;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
             g_finish[b & 0x3ffffu] = t_;

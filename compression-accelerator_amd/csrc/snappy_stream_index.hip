@@ -24,7 +24,9 @@
 #include <stdlib.h>
 
 #include "wave_utils.h"
-#include <stdio.h>
+#if defined(SZ_STREAM_DEBUG) || defined(SZ_DEBUG_SYNC)
+#include <stdio.h>  // (diagnostic builds only: tools/streamdbg.py, the launch-by-launch synchronisation)
+#endif
 
 namespace szk {
 
@@ -444,6 +446,12 @@ __global__ __launch_bounds__(64) void stream_chunk_maps_kernel(uint32_t n, uint3
 }
 
 #ifdef SZ_STREAM_DEBUG
+__device__ uint32_t g_bnd_dbg;  // (debug builds: the boundaries pass's slowest wave, reported by stream_debug_report_kernel)
+__global__ void stream_debug_report_kernel()
+{
+    printf("boundaries pass: most windows walked by one wave %u (segment %u mod 8192)\n", g_bnd_dbg >> 13, g_bnd_dbg & 8191u);
+    g_bnd_dbg = 0;
+}
 __device__ unsigned long long g_res_dbg[16];  // (debug builds: counts and clocks of the serial pass; tools/streamdbg.py)
 #define RES_COUNT(i, v) do { if (lane == 0) g_res_dbg[i] += (v); } while (0)
 #define RES_CLOCK(t) unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory")
@@ -841,7 +849,7 @@ __global__ __launch_bounds__(64) void stream_boundaries_kernel(const uint8_t *__
         unsigned long long dbg_t1;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_t1) :: "memory");
         if (lane == 0)
-            atomicMax(flag + 1, (dbg_windows << 13) | (s & 8191u));  // most windows walked by a wave, its segment
+            atomicMax(&g_bnd_dbg, (dbg_windows << 13) | (s & 8191u));  // most windows walked by a wave, its segment (never into the API's result words)
         (void)dbg_t0;
     }
 #endif
@@ -1028,6 +1036,9 @@ hipError_t launch_stream_index(const void *d_in, uint64_t n, uint32_t body, uint
     hipLaunchKernelGGL(stream_boundaries_kernel, dim3(n_seg), dim3(64), 0, stream, in, (uint32_t)n, (uint32_t)ulen,
                        n_seg, seg_shift, entries, maps, chk, off, d_result + 1, covered);
     SZ_DBG_SYNC("stream_boundaries_kernel");
+#ifdef SZ_STREAM_DEBUG
+    hipLaunchKernelGGL(stream_debug_report_kernel, dim3(1), dim3(1), 0, stream);
+#endif
     return hipGetLastError();
 }
 

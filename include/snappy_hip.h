@@ -72,15 +72,22 @@ extern "C" {
 #define SZ_FLAG_BLOCK_VARINT 1u   /* prepend varint32(in_len) to every block: each slot is a
                                      self-contained Snappy raw stream (== snappy::RawCompress of
                                      that block).  Without it slots hold fragment bodies only. */
-#define SZ_FLAG_HW_COMPAT 2u      /* sz_compress_blocks_hip only: NOT software Snappy's bytes but the element stream the
-                                     reference accelerator's own datapath forms for the block (512-entry table, every
-                                     position hashed, 60-byte literals, 64-byte copies chained by `continue`:
-                                     src/main/scala/example/{HashTable,MatchFinder,CopyCompress,CompressionAccelerator}.scala;
-                                     SURVEY 8f-4).  Valid Snappy elements -- with SZ_FLAG_BLOCK_VARINT any Snappy decoder
-                                     reads the slot back -- and larger than Snappy's.  The length the RTL reports
-                                     (benchmark/hw_results.csv) is this stream's size + the size of varint32(n) + 1 if
-                                     the stream ends with a literal, on 31 of its 36 rows (tests/test_hw_model.py).  One
-                                     wavefront per block, 64 positions per step: a compatibility mode, not a fast path. */
+#define SZ_FLAG_HW_COMPAT 2u      /* sz_compress_blocks_hip only: NOT software Snappy's bytes but the element stream of a
+                                     FUNCTIONAL MODEL of the reference accelerator's datapath, read from its RTL by hand
+                                     (512-entry table, every position hashed, 60-byte literals, 64-byte copies chained by
+                                     `continue`: src/main/scala/example/{HashTable,MatchFinder,CopyCompress,
+                                     CompressionAccelerator}.scala; checker tests/hw_model.py).  Valid Snappy
+                                     elements -- with SZ_FLAG_BLOCK_VARINT any Snappy decoder reads the slot back -- and
+                                     larger than Snappy's.  Fidelity to the hardware is pinned by SIZES only, and only
+                                     in part: the length the RTL reports (benchmark/hw_results.csv) is this stream's
+                                     size + the size of varint32(n) + 1 if the stream ends with a literal on 31 of its
+                                     36 rows; on repeat-5000 and on every `real` row of 5 000 bytes or more (text whose
+                                     tail repeats its head 4 185 bytes back) the hardware reports 8 and 204..1 257 bytes
+                                     MORE than this model (tests/test_hw_model.py) -- its pipeline loses or breaks far
+                                     matches in a way that depends on cycle-level timing of modules that are not in the
+                                     reference tree (the scratchpad and its DMA).  Not "the accelerator's format" beyond
+                                     that evidence.  One wavefront per block, 64 positions per step: a compatibility
+                                     mode, not a fast path. */
 
 /* RoCC command surface constants (tests/compression.c:8-15) */
 #define SZ_ROCC_CHANNEL 3
