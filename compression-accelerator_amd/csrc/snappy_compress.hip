@@ -441,7 +441,6 @@ struct WaveTeam {
     unsigned long long *trace;  // (-DSZ_TRACE builds: this wave's stamps for this block, or null)
     uint8_t *scr;    // LDS: 256 bytes of scratch of this wave's own (lanes that share a bucket inside a tile)
     uint32_t *bar;   // LDS: arrivals at the team's barrier (the workgroup may hold waves that are not of the team)
-    const uint32_t *dead;  // LDS: non-zero once a wave of the team has given up (every wave then leaves)
 };
 static constexpr uint32_t kTeamDoneTurn = 0x3fffffu;  // turn field of a token: the block is finished
 static constexpr uint32_t kTeamNotMine = 0xfffffffcu; // return value of the waves that did not finish the block
@@ -485,7 +484,7 @@ __device__ __forceinline__ void team_publish(uint64_t *slot, uint64_t v)
 // kernel's workgroups hold waves that compress other blocks): a counter of arrivals that only grows; a wave waits
 // until the count has passed the multiple of kWaves its own arrival belongs to.  LDS accesses of a wave made
 // before its arrival are complete before it (the wait), those of the others are visible after it.
-template <int W>
+template <int W, bool kWatchDead>
 __device__ __forceinline__ uint32_t team_barrier(uint32_t *bar, const uint32_t *dead, uint32_t lane)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -501,7 +500,7 @@ __device__ __forceinline__ uint32_t team_barrier(uint32_t *bar, const uint32_t *
             lost = 0;
             break;
         }
-        if (uni(__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0)
+        if (kWatchDead && uni(__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0)
             break;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -708,8 +707,11 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 const uint32_t nvec = (1u << log2T) >> 3;
                 for (uint32_t i = team.wave * 64u + lane; i < nvec; i += 64u * kTeamW)
                     reinterpret_cast<u32x4 *>(tab.lds)[i] = u32x4{0, 0, 0, 0};
-                if (__builtin_expect(team_barrier<kTeamW>(team.bar, team.dead, lane) != 0, 0))
-                    return kTeamLost;  // (the table is not known to be clear: the kernel poisons the block)
+                // (a lost barrier: the table is not known to be clear -- the main loop is left at its first test and
+                // the wave returns kTeamLost, the kernel poisons the block)
+                team_lost = team_barrier<kTeamW, false>(team.bar, nullptr, lane) != 0;
+                team_gone = team_lost;
+                poisoned = team_lost;
             } else {
                 tab.clear(log2T, lane);
             }
@@ -2411,22 +2413,46 @@ static constexpr int kTeamWaves = SZ_TEAM_WAVES > 1 ? SZ_TEAM_WAVES : 2;
 static constexpr int kLoneWaves = SZ_LONE_WAVES;
 static constexpr int kHybridWaves = kTeamWaves + kLoneWaves;
 static constexpr int kHybridPerSimd = kHybridWaves;  // four workgroups per CU, one wave of each per SIMD
-__global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_eu(kHybridPerSimd, kHybridPerSimd))) void compress_blocks_team_kernel(
-    const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
-    uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
-    uint32_t *__restrict__ out_len, uint32_t flags, uint16_t *scratch_tables, uint32_t *__restrict__ select,
-    const uint32_t *__restrict__ queue, uint32_t auto_mode)
+// The team kernel's arguments as ONE struct passed by value: it lies at offset 0 of the kernel-argument segment, and
+// the persistent loops read its fields from there (scalar loads through a laundered pointer) where they need them
+// instead of holding ~22 scalar registers of arguments across the per-block code, which has none to spare (the
+// parse state alone fills the scalar file: 116-124 scalar spills in this kernel).
+struct TeamArgs {
+    const uint8_t *src;
+    uint64_t in_stride;
+    const uint32_t *in_len;
+    uint64_t total_len;
+    uint8_t *dst;
+    uint64_t dst_stride;
+    uint32_t *out_len;
+    uint16_t *scratch_tables;
+    uint32_t *select;
+    const uint32_t *queue;
+    uint32_t n_blocks, flags, auto_mode;
+};
+__global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_eu(kHybridPerSimd, kHybridPerSimd))) void compress_blocks_team_kernel(TeamArgs args_in_kernarg)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
     __shared__ __attribute__((aligned(16))) uint64_t tokens[2];
     __shared__ __attribute__((aligned(16))) uint8_t dup_scr[kTeamWaves * 256];
     __shared__ uint32_t lone_bm[(kLoneWaves > 0 ? kLoneWaves : 1) * 512];  // one 16384-bit bitmap per global-table wave
     __shared__ uint32_t next_block, team_bar, team_dead, len_claim;
-    if ((auto_mode & 1u) && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
-        return;
-    if ((auto_mode & 2u) && (auto_mode & 1u) && !launch_is_mixed(select))
-        queue = nullptr;  // an order queue, and the sample found one kind of block only: it was not filled
-    const uint32_t n_work = queue ? uni(select[3]) : n_blocks;
+    (void)args_in_kernarg;
+    using KArgs = const __attribute__((address_space(4))) TeamArgs;
+    auto ka = [&]() -> KArgs * {  // a fresh look at the arguments: what is read through it is not kept alive from an earlier look
+        KArgs *p = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return p;
+    };
+    bool use_queue = ka()->queue != nullptr;
+    {
+        const uint32_t auto_mode = ka()->auto_mode;
+        if ((auto_mode & 1u) && !prefers_dual(ka()->select))  // auto mode: incompressible sample, the single kernel ran
+            return;
+        if ((auto_mode & 2u) && (auto_mode & 1u) && !launch_is_mixed(ka()->select))
+            use_queue = false;  // an order queue, and the sample found one kind of block only: it was not filled
+    }
+    const uint32_t n_work = use_queue ? uni(ka()->select[3]) : ka()->n_blocks;
     if (blockIdx.x * (1u + kLoneWaves) >= n_work)
         return;
     const uint32_t wave = uni(threadIdx.x >> 6);
@@ -2434,13 +2460,15 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
     auto next_index = [&]() -> uint32_t {  // one queue for the whole grid (address through VGPRs: see the multi-wave kernel)
         uint32_t b0 = 0;
         if (lane == 0) {
-            uint64_t qa = (uint64_t)(uintptr_t)(select + 2);
+            uint64_t qa = (uint64_t)(uintptr_t)(ka()->select + 2);
             uint32_t qlo = (uint32_t)qa, qhi = (uint32_t)(qa >> 32);
             asm volatile("" : "+v"(qlo), "+v"(qhi));
             b0 = atomicAdd(reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)qhi << 32) | qlo)), 1u);
         }
         return uni(b0);
     };
+    auto queued = [&](uint32_t i) -> uint32_t { return use_queue ? uni(ka()->queue[i]) : i; };
+    auto store_len = [&](uint32_t b, uint32_t v) { ka()->out_len[b] = v; };  // every lane, same address, same value
     if (threadIdx.x == 0) {
         __hip_atomic_store(&team_bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&team_dead, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2452,36 +2480,36 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
         const uint32_t lw = wave - kTeamWaves;
         for (uint32_t i = lane; i < 512; i += 64)
             lone_bm[lw * 512u + i] = 0;
-        uint16_t *my_glob = scratch_tables + (size_t)(blockIdx.x * (kLoneWaves > 0 ? kLoneWaves : 1) + lw) * kMaxTable;
-        const HashTab<false> gtab{nullptr, my_glob, lone_bm + lw * 512u};
         for (;;) {
             uint32_t b = next_index();
             if (b >= n_work)
                 break;
-            if (queue)
-                b = uni(queue[b]);
-            const uint32_t n = block_length(in_len, total_len, in_stride, b);
+            b = queued(b);
+            KArgs *a = ka();
+            const uint32_t n = block_length(a->in_len, a->total_len, a->in_stride, b);
             if (n > kMaxBlock) {
-                out_len[b] = 0xffffffffu;
+                store_len(b, 0xffffffffu);
                 continue;
             }
-            const uint32_t op = compress_one_block<0, true>(gtab, src + (uint64_t)b * in_stride, n,
-                                                            dst + (uint64_t)b * dst_stride, flags, lane);
+            uint16_t *my_glob = a->scratch_tables + (size_t)(blockIdx.x * (kLoneWaves > 0 ? kLoneWaves : 1) + lw) * kMaxTable;
+            const HashTab<false> gtab{nullptr, my_glob, lone_bm + lw * 512u};
+            const uint32_t op = compress_one_block<0, true>(gtab, a->src + (uint64_t)b * a->in_stride, n,
+                                                            a->dst + (uint64_t)b * a->dst_stride, a->flags, lane);
 #ifdef SZ_EXP_COUNT
-            out_len[b] = op | 0x80000000u;  // (tools/rolecount.hip: a block done by a lone wave)
+            store_len(b, op | 0x80000000u);  // (tools/rolecount.hip: a block done by a lone wave)
             {
                 unsigned long long t_;
                 asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");  // (100 MHz, one clock for the whole GPU)
                 g_finish[b & 0x3ffffu] = t_;  // (every lane, same address, same value)
             }
 #else
-            out_len[b] = op;
+            store_len(b, op);
 #endif
         }
         return;
     }
     const HashTab<true> tab{lds_tab, nullptr, nullptr};
-    WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr, dup_scr + wave * 256u, &team_bar, &team_dead};
+    WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr, dup_scr + wave * 256u, &team_bar};
     __builtin_amdgcn_s_setprio(SZ_TEAM_BASE_PRIO);  // (a team's waves go before the lone ones; the token's holder before both)
     // Giving up (a wave of the team stalled for seconds: SZ_TEAM_SPIN_CAP): the wave that gives up raises
     // `team_dead` and every wave of the team leaves the persistent loop at its next look at it -- the barrier's
@@ -2495,7 +2523,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             const uint32_t b0 = next_index();
             __hip_atomic_store(&next_block, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        uint32_t lost = team_barrier<kTeamWaves>(&team_bar, &team_dead, lane);  // every wave of the team is past the block before (it left on the "done" token)
+        uint32_t lost = team_barrier<kTeamWaves, true>(&team_bar, &team_dead, lane);  // every wave of the team is past the block before (it left on the "done" token)
         uint32_t b = uni(__hip_atomic_load(&next_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (wave == 0 && lost == 0) {  // only now: a wave still polling for "done" must not find an empty token instead
             __hip_atomic_store(&tokens[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2503,31 +2531,28 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             __hip_atomic_store(&len_claim, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (lost == 0)
-            lost = team_barrier<kTeamWaves>(&team_bar, &team_dead, lane);  // (everyone has the index and sees fresh tokens before any wave goes on)
+            lost = team_barrier<kTeamWaves, true>(&team_bar, &team_dead, lane);  // (everyone has the index and sees fresh tokens before any wave goes on)
         if (__builtin_expect(lost != 0, 0)) {
             __hip_atomic_store(&team_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (wave == 0 && b < n_work) {  // (wave 0 took this index out of the queue: nobody else will report on it)
-                if (queue)
-                    b = uni(queue[b]);
-                out_len[b] = 0xfffffffeu;
-            }
+            if (wave == 0 && b < n_work)  // (wave 0 took this index out of the queue: nobody else will report on it)
+                store_len(queued(b), 0xfffffffeu);
             break;
         }
         if (b >= n_work)
             break;
-        if (queue)
-            b = uni(queue[b]);
-        const uint32_t n = block_length(in_len, total_len, in_stride, b);
+        b = queued(b);
+        KArgs *a = ka();
+        const uint32_t n = block_length(a->in_len, a->total_len, a->in_stride, b);
         if (n > kMaxBlock) {
             if (wave == 0)
-                out_len[b] = 0xffffffffu;
+                store_len(b, 0xffffffffu);
             continue;
         }
 #ifdef SZ_TRACE
         team.trace = b < kTraceBlocks && g_trace ? g_trace + ((size_t)b * kTeamWaves + wave) * kTraceCap : nullptr;
 #endif
         const uint32_t op = compress_one_block<0, true, HashTab<true>, false, true, SZ_MATCH_PIECES, WaveTeam<kTeamWaves>>(
-            tab, src + (uint64_t)b * in_stride, n, dst + (uint64_t)b * dst_stride, flags, lane, team);
+            tab, a->src + (uint64_t)b * a->in_stride, n, a->dst + (uint64_t)b * a->dst_stride, a->flags, lane, team);
         if (op != kTeamNotMine) {
             // (a9) the wave that finished the block, or the first wave that gave it up: every lane, same address, same value
             uint32_t first = 0;
@@ -2537,7 +2562,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             if (op == kTeamLost)
                 __hip_atomic_store(&team_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (first == 0)
-                out_len[b] = op == kTeamLost ? 0xfffffffeu : op;
+                store_len(b, op == kTeamLost ? 0xfffffffeu : op);
             if (op == kTeamLost)
                 break;
         }
@@ -2629,9 +2654,9 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
             uint32_t tgrid = (n_blocks + kLoneWaves) / (1u + kLoneWaves);
             tgrid = tgrid < dual->n_slots ? tgrid : dual->n_slots;
             static_assert(kLoneWaves <= (int)kDualTablesPerGroup, "the workspace has kDualTablesPerGroup tables per workgroup");
-            hipLaunchKernelGGL(compress_blocks_team_kernel, dim3(tgrid), dim3(64 * kHybridWaves), 0, stream, src, in_stride,
-                               d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->tables, dual->select,
-                               work_queue, (sampled ? 1u : 0u) | (ordered ? 2u : 0u));
+            const TeamArgs targs{src, in_stride, d_in_len, total_len, dst, dst_stride, d_out_len, dual->tables, dual->select,
+                                 work_queue, n_blocks, flags, (sampled ? 1u : 0u) | (ordered ? 2u : 0u)};
+            hipLaunchKernelGGL(compress_blocks_team_kernel, dim3(tgrid), dim3(64 * kHybridWaves), 0, stream, targs);
             return hipGetLastError();
         }
         uint32_t grid = (n_blocks + kGroupWaves - 1) / kGroupWaves;
