@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "sz_uncompress_stream_hip", "sz_compress", "sz_uncompress", "sz_get_uncompressed_length",
     "sz_rocc_cmd", "rocc_cmd", "sz_rocc_last_error", "sz_release_thread_resources",
     "sz_release_stream_resources", "sz_shard_range", "sz_stream_offsets", "sz_device_count",
-    "sz_last_hip_error", "sz_strerror", "sz_version",
+    "sz_last_hip_error", "sz_strerror", "sz_version", "sz_profile_next_launch",
 )
 
 
@@ -104,6 +104,8 @@ def lib():
     L.sz_strerror.argtypes = [i32]
     L.sz_strerror.restype = ctypes.c_char_p
     L.sz_version.restype = ctypes.c_char_p
+    L.sz_profile_next_launch.argtypes = [vp, vp, vp, vp]
+    L.sz_profile_next_launch.restype = i32
     _lib = L
     return L
 
@@ -148,6 +150,14 @@ def compress_blocks(src, in_stride, n_blocks, in_len=None, dst=None, dst_stride=
                                         _ptr(out_len), (FLAG_BLOCK_VARINT if varint else 0) | (FLAG_HW_COMPAT if hw_compat else 0),
                                         _stream_handle(stream)), "sz_compress_blocks_hip")
     return dst, out_len
+
+
+def profile_next_launch(single_start=None, single_stop=None, multi_start=None, multi_stop=None):
+    """Raw hipEvent_t handles (integers) to be recorded around the dominant kernels of this thread's next compress
+    launch (include/snappy_hip.h: sz_profile_next_launch)."""
+    _check(lib().sz_profile_next_launch(*(ctypes.c_void_p(e) if e else None
+                                          for e in (single_start, single_stop, multi_start, multi_stop))),
+           "sz_profile_next_launch")
 
 
 def compress_stream(src, n, slots=None, slot_stride=SLOT_STRIDE, lens=None, varint=False, stream=None):

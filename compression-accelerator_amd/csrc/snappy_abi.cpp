@@ -370,6 +370,13 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
     return SZ_OK;
 }
 
+int sz_profile_next_launch(void *single_start, void *single_stop, void *multi_start, void *multi_stop)
+{
+    szk::set_profile_events(static_cast<hipEvent_t>(single_start), static_cast<hipEvent_t>(single_stop),
+                            static_cast<hipEvent_t>(multi_start), static_cast<hipEvent_t>(multi_stop));
+    return SZ_OK;
+}
+
 int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t slot_stride,
                            uint32_t *d_len, uint32_t flags, void *stream)
 {

@@ -721,11 +721,12 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     reinterpret_cast<u32x4 *>(tab.lds)[i] = u32x4{0, 0, 0, 0};
                 // (a lost barrier: the table is not known to be clear -- the main loop is left at its first test and
                 // the wave returns kTeamLost, the kernel poisons the block)
-                team_lost = team_barrier<kTeamW, false>(team.bar, nullptr, lane) != 0;
+                team_lost = uni(team_barrier<kTeamW, false>(team.bar, nullptr, lane)) != 0;
                 team_gone = team_lost;
                 poisoned = team_lost;
             } else {
                 tab.clear(log2T, lane);
+                UNIFORM_JOIN();  // (the per-lane loop's join is not this arm's join with the one above: team_gone stays provably uniform)
             }
         } else {
             tab.clear(log2T, lane);
@@ -2470,7 +2471,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
         if ((auto_mode & 2u) && (auto_mode & 1u) && !launch_is_mixed(ka()->select))
             use_queue = false;  // an order queue, and the sample found one kind of block only: it was not filled
     }
-    const uint32_t n_work = use_queue ? uni(ka()->select[3]) : ka()->n_blocks;
+    const uint32_t n_work = use_queue ? uni(ka()->select[3]) : uni(ka()->n_blocks);
     if (blockIdx.x * (1u + kLoneWaves) >= n_work)
         return;
     const uint32_t wave = uni(threadIdx.x >> 6);
@@ -2503,16 +2504,20 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             if (b >= n_work)
                 break;
             b = queued(b);
+            // (what is read through the laundered pointer is uniform -- scalar loads from the argument segment -- but
+            // not PROVABLY so for the compiler's uniformity analysis: said so here, tests/test_abi.py checks the proof)
             KArgs *a = ka();
-            const uint32_t n = block_length(a->in_len, a->total_len, a->in_stride, b);
+            const uint32_t n = uni(block_length(a->in_len, a->total_len, a->in_stride, b));
             if (n > kMaxBlock) {
                 store_len(b, 0xffffffffu);
                 continue;
             }
-            uint16_t *my_glob = a->scratch_tables + (size_t)(blockIdx.x * (kLoneWaves > 0 ? kLoneWaves : 1) + lw) * kMaxTable;
+            uint16_t *my_glob = reinterpret_cast<uint16_t *>(uni64((uint64_t)(uintptr_t)a->scratch_tables)) +
+                                (size_t)(blockIdx.x * (kLoneWaves > 0 ? kLoneWaves : 1) + lw) * kMaxTable;
             const HashTab<false> gtab{nullptr, my_glob, lone_bm + lw * 512u};
-            const uint32_t op = compress_one_block<0, true>(gtab, a->src + (uint64_t)b * a->in_stride, n,
-                                                            a->dst + (uint64_t)b * a->dst_stride, a->flags, lane);
+            const uint8_t *in_b = reinterpret_cast<const uint8_t *>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
+            uint8_t *out_b = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
+            const uint32_t op = compress_one_block<0, true>(gtab, in_b, n, out_b, uni(a->flags), lane);
 #ifdef SZ_EXP_COUNT
             store_len(b, op | 0x80000000u);  // (tools/rolecount.hip: a block done by a lone wave)
             {
@@ -2560,7 +2565,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             break;
         b = queued(b);
         KArgs *a = ka();
-        const uint32_t n = block_length(a->in_len, a->total_len, a->in_stride, b);
+        const uint32_t n = uni(block_length(a->in_len, a->total_len, a->in_stride, b));
         if (n > kMaxBlock) {
             if (wave == 0)
                 store_len(b, 0xffffffffu);
@@ -2569,14 +2574,14 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
 #ifdef SZ_TRACE
         team.trace = b < kTraceBlocks && g_trace ? g_trace + ((size_t)b * kTeamWaves + wave) * kTraceCap : nullptr;
 #endif
+        const uint8_t *in_b = reinterpret_cast<const uint8_t *>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
+        uint8_t *out_b = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
         const uint32_t op = compress_one_block<0, true, HashTab<true>, false, true, SZ_MATCH_PIECES, WaveTeam<kTeamWaves>>(
-            tab, a->src + (uint64_t)b * a->in_stride, n, a->dst + (uint64_t)b * a->dst_stride, a->flags, lane, team);
+            tab, in_b, n, out_b, uni(a->flags), lane, team);
         if (op != kTeamNotMine) {
             // (a9) the wave that finished the block, or the first wave that gave it up: every lane, same address, same value
-            uint32_t first = 0;
-            if (lane == 0)
-                first = __hip_atomic_exchange(&len_claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            first = uni(first);
+            // (every lane adds one: the lanes of a wave are served one after the other, the wave whose first lane reads 0 has the claim)
+            const uint32_t first = uni(__hip_atomic_fetch_add(&len_claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             if (op == kTeamLost)
                 __hip_atomic_store(&team_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (first == 0)
@@ -2617,12 +2622,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
 
 // ------------------------------------------------------------------------------ launchers
 
+// sz_profile_next_launch: events around the two kernels that can be a launch's dominant one (see snappy_kernels.h)
+struct ProfileEvents {
+    hipEvent_t single0 = nullptr, single1 = nullptr, multi0 = nullptr, multi1 = nullptr;
+};
+static thread_local ProfileEvents tl_profile;
+void set_profile_events(hipEvent_t single0, hipEvent_t single1, hipEvent_t multi0, hipEvent_t multi1)
+{
+    tl_profile = ProfileEvents{single0, single1, multi0, multi1};
+}
+
 static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len, uint64_t total_len,
                              uint32_t n_blocks, void *d_dst, uint64_t dst_stride, uint32_t *d_out_len,
                              uint32_t flags, const DualScratch *dual, hipStream_t stream)
 {
     const uint8_t *src = static_cast<const uint8_t *>(d_src);
     uint8_t *dst = static_cast<uint8_t *>(d_dst);
+    const ProfileEvents prof = tl_profile;  // (one shot)
+    tl_profile = ProfileEvents{};
     // fixed small blocks: their own kernel (measured: 2.4x on incompressible 4 KiB pages, 1.6x on text
     // pages, 1.45x / 1.0x at 8 KiB; from 16 KiB on its 32 KiB table leaves one wave per SIMD and it loses)
     if (!d_in_len && total_len == 0 && in_stride <= kSmallBlockMax) {
@@ -2647,10 +2664,15 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
     }
     // route mode: the single kernel starts every block and leaves the compressible ones, marked in
     // out_len, to the multi-wave kernel behind it on the stream (no host sync either)
-    if (!dual_ok || sampled || route)
+    if (!dual_ok || sampled || route) {
+        if (prof.single0)
+            (void)hipEventRecord(prof.single0, stream);
         hipLaunchKernelGGL(compress_blocks_kernel, dim3(n_blocks), dim3(64), 0, stream, src, in_stride, d_in_len,
-                           total_len, n_blocks, dst, dst_stride, d_out_len, flags, route ? 1u : 0u,
-                           sampled ? dual->select : (const uint32_t *)nullptr);
+                               total_len, n_blocks, dst, dst_stride, d_out_len, flags, route ? 1u : 0u,
+                               sampled ? dual->select : (const uint32_t *)nullptr);
+        if (prof.single1)
+            (void)hipEventRecord(prof.single1, stream);
+    }
     if (route)
         hipLaunchKernelGGL(compact_routed_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, d_out_len, n_blocks,
                            dual->queue, dual->select);
@@ -2674,14 +2696,22 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
             static_assert(kLoneWaves <= (int)kDualTablesPerGroup, "the workspace has kDualTablesPerGroup tables per workgroup");
             const TeamArgs targs{src, in_stride, d_in_len, total_len, dst, dst_stride, d_out_len, dual->tables, dual->select,
                                  work_queue, n_blocks, flags, (sampled ? 1u : 0u) | (ordered ? 2u : 0u)};
+            if (prof.multi0)
+                (void)hipEventRecord(prof.multi0, stream);
             hipLaunchKernelGGL(compress_blocks_team_kernel, dim3(tgrid), dim3(64 * kHybridWaves), 0, stream, targs);
+            if (prof.multi1)
+                (void)hipEventRecord(prof.multi1, stream);
             return hipGetLastError();
         }
         uint32_t grid = (n_blocks + kGroupWaves - 1) / kGroupWaves;
         grid = grid < dual->n_slots ? grid : dual->n_slots;
+        if (prof.multi0)
+            (void)hipEventRecord(prof.multi0, stream);
         hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(64 * kGroupWaves), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->tables,
                            dual->select, work_queue, (sampled ? 1u : 0u) | (ordered ? 2u : 0u));
+        if (prof.multi1)
+            (void)hipEventRecord(prof.multi1, stream);
     }
     return hipGetLastError();
 }

@@ -37,6 +37,12 @@ hipError_t launch_compress_blocks(const void *d_src, uint64_t in_stride, const u
                                   uint32_t *d_out_len, uint32_t flags, const DualScratch *dual,
                                   hipStream_t stream);
 
+// Measurement hook (sz_profile_next_launch): the next launch_compress_blocks / launch_compress_stream of THIS host
+// thread records single[0] / single[1] right around the launch of compress_blocks_kernel and multi[0] / multi[1]
+// right around the persistent kernel's (team or multi-wave), on the launch's stream; null events are skipped.
+// One shot: cleared by the launch that used it.
+void set_profile_events(hipEvent_t single0, hipEvent_t single1, hipEvent_t multi0, hipEvent_t multi1);
+
 // SZ_FLAG_HW_COMPAT (snappy_hwcompat.hip): the element stream of the reference accelerator's own datapath, one wave per job
 constexpr uint32_t kFlagHwCompat = 2u;  // == SZ_FLAG_HW_COMPAT
 hipError_t launch_compress_hw_blocks(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len, uint64_t total_len,

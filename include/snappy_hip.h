@@ -109,6 +109,14 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
                            uint32_t n_blocks, void *d_dst, size_t dst_stride,
                            uint32_t *d_out_len, uint32_t flags, void *stream);
 
+/* Measurement hook (bench.py's `roofline.achieved`; no reference counterpart): the NEXT sz_compress_blocks_hip /
+ * sz_compress_stream_hip call of the calling host thread records the given hipEvent_t handles on its stream right
+ * around the launch of the kernel that can be the launch's dominant one -- single_start / single_stop around the
+ * one-wavefront-per-block kernel, multi_start / multi_stop around the persistent kernel for compressible launches
+ * (both are enqueued when a data sample chooses between them; the one not chosen exits at once).  NULL handles are
+ * skipped; one shot.  Events are created and read by the caller (hipEventCreate, hipEventElapsedTime). */
+int sz_profile_next_launch(void *single_start, void *single_stop, void *multi_start, void *multi_stop);
+
 /* Same kernel for ONE contiguous input of n bytes (n < 2^32) cut into consecutive 64 KiB fragments
  * (the last one ragged): fragment k goes to d_slots + k*slot_stride, its length to d_len[k].
  * Number of fragments = ceil(n / 65536).  This is the fragment loop of snappy::Compress. */
