@@ -309,7 +309,19 @@ int sz_device_count(void)
 
 int sz_last_hip_error(void) { return tl_hip_error; }
 
-const char *sz_version(void) { return "snappy_hip 0.1 (gfx950; Snappy 1.1.8 bit-exact)"; }
+// (the compiler the kernels were built with is part of the version: their speed -- and once their liveness -- has
+// depended on how one clang merged branches and allocated registers; csrc/Makefile warns when it is not the one the
+// numbers under profiles/ were measured with)
+#define SZ_STR2(x) #x
+#define SZ_STR(x) SZ_STR2(x)
+const char *sz_version(void)
+{
+    return "snappy_hip 0.4 (gfx950; Snappy 1.1.8 bit-exact; built with clang " SZ_STR(__clang_major__) "." SZ_STR(__clang_minor__) "." SZ_STR(__clang_patchlevel__)
+#ifdef SZ_TOOLCHAIN
+           ", " SZ_TOOLCHAIN
+#endif
+           ")";
+}
 
 const char *sz_strerror(int code)
 {
