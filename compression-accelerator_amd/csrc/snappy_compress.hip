@@ -616,7 +616,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         // the block's first bytes: they are kept in registers (general code of the instances that have registers to
         // spare), and a batch of probes in which NO lane has a real candidate -- every batch of an incompressible
         // block -- then does without the candidate loads, i.e. without a memory round trip of its own (an
-        // incompressible 64 KiB block had 7 dependent round trips, ~3 us each under load; 1 is left: C3 +5 %).
+        // incompressible 64 KiB block had 7 dependent round trips, ~3 us each under load; about two are left: C3 +2 %,
+        // EXPERIMENTS.md R4.2).
         constexpr bool kZeroCand = !kLean;
         const bool zok = kZeroCand && n >= 64;
         u32x4 z0 = {0, 0, 0, 0}, z1 = {0, 0, 0, 0};
@@ -2580,11 +2581,12 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             tab, in_b, n, out_b, uni(a->flags), lane, team);
         if (op != kTeamNotMine) {
             // (a9) the wave that finished the block, or the first wave that gave it up: every lane, same address, same value
-            // (every lane adds one: the lanes of a wave are served one after the other, the wave whose first lane reads 0 has the claim)
-            const uint32_t first = uni(__hip_atomic_fetch_add(&len_claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            // (every lane adds one; exactly one lane of one wave reads 0, and that wave has the claim -- whichever
+            // lane it is: nothing is assumed about the order in which an instruction's lanes are served)
+            const bool mine = __ballot(__hip_atomic_fetch_add(&len_claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) != 0;
             if (op == kTeamLost)
                 __hip_atomic_store(&team_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (first == 0)
+            if (mine)
                 store_len(b, op == kTeamLost ? 0xfffffffeu : op);
             if (op == kTeamLost)
                 break;
