@@ -257,7 +257,7 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
             kernel_name = "szk::compress_blocks_kernel"
         else:
             kernel_ms.append(m_ms)
-            kernel_name = "szk::compress_blocks_team_kernel" if os.environ.get("SZ_KERNEL") not in ("dual", "route") else "szk::compress_blocks_dual_kernel"
+            kernel_name = "szk::compress_blocks_team_kernel" if os.environ.get("SZ_KERNEL") != "dual" else "szk::compress_blocks_dual_kernel"
     hev.close()
 
     # ---- checks, outside the timed region: EVERY block against the oracle (bytes and lengths)

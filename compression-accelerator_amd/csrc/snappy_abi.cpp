@@ -58,11 +58,10 @@ int kernel_mode()
     // default (auto): when there are enough blocks to give every SIMD two waves, a sample of the data decides
     // between the single kernel (incompressible) and the team kernel (compressible).  SZ_KERNEL=single: always
     // the single kernel; team: always the team kernel, from two blocks up; dual: always the multi-wave kernel
-    // (round 1-2's kernel for compressible data, kept for comparison), from two blocks up; route: per block
-    // inside the launch (the single kernel hands compressible blocks to the multi-wave kernel).  Read on every
-    // call so that a test can switch modes inside one process.
+    // (round 1-2's kernel for compressible data, kept as a second implementation for differential tests and A/B),
+    // from two blocks up.  Read on every call so that a test can switch modes inside one process.
     const char *e = getenv("SZ_KERNEL");
-    return !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : strcmp(e, "route") == 0 ? 3 : strcmp(e, "team") == 0 ? 4 : 0;
+    return !e ? 0 : strcmp(e, "single") == 0 ? 1 : strcmp(e, "dual") == 0 ? 2 : strcmp(e, "team") == 0 ? 4 : 0;
 }
 
 // The workspace slot of (current device, stream) for a launch of n_blocks, or nullptr when the
@@ -123,10 +122,10 @@ std::shared_ptr<DualSlot> dual_slot_for(hipStream_t stream, uint32_t n_blocks, s
     }
     std::shared_ptr<DualSlot> s = it->second;
     *view = s->sc;
-    view->mode = (mode == 2 || mode == 4) ? szk::kDualAlways : mode == 3 ? szk::kDualRoute : szk::kDualAuto;
+    view->mode = (mode == 2 || mode == 4) ? szk::kDualAlways : szk::kDualAuto;
     // compressible launches: the team kernel (a two-wave team on the LDS table + two global-table waves per
-    // workgroup), unless the multi-wave kernel is asked for by name (SZ_KERNEL=dual; route hands its blocks to it too)
-    view->kernel = (mode == 2 || mode == 3) ? szk::kKernelMulti : szk::kKernelTeam;
+    // workgroup), unless the multi-wave kernel is asked for by name (SZ_KERNEL=dual)
+    view->kernel = mode == 2 ? szk::kKernelMulti : szk::kKernelTeam;
     view->min_blocks = (mode == 2 || mode == 4) ? 2u : 2u * s->sc.n_slots;
     if (n_blocks < view->min_blocks)
         return nullptr;

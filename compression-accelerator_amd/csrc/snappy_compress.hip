@@ -546,14 +546,10 @@ __device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t tur
 }
 
 // One block by one wavefront.  kChunks = 1 KiB chunks of the block kept in registers.
-// Auto mode routes blocks between the two kernels: the single kernel (kRoute) gives a block up as
-// soon as it has emitted its first copy and marks it for the multi-wave kernel.
-static constexpr uint32_t kRoutedMarker = 0xfffffffdu;  // in out_len[b]: "compressible, not done yet"
-
 // kFast: with the fast dense path (compressible data).  The single kernel's instance for launches that
 // a sample found incompressible is built without it: its presence alone costs that instance 2 % (register
 // allocation of the strided path), and such blocks do not use it.
-template <int kBlkChunks, bool kLean, typename Tab, bool kRoute = false, bool kFast = true,
+template <int kBlkChunks, bool kLean, typename Tab, bool kFast = true,
           int kMatchPieces = SZ_MATCH_PIECES, typename TeamT = NoTeam>
 __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uint8_t *__restrict__ in,
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
@@ -798,8 +794,6 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             op = uni(op); kcur = uni(kcur); trips = uni(trips); poisoned = unib(poisoned); hold_fast = unib(hold_fast);
             prepW = uni(prepW); prepC = unib(prepC); prepped = unib(prepped); first_scan = unib(first_scan);
             big_len = uni(big_len);
-            if (kRoute && chain)  // the first copy of this block: compressible data, the multi-wave kernel takes it
-                return kRoutedMarker;
             if (poisoned || ++trips > 2u * kMaxBlock) {
                 poisoned = true;
                 break;
@@ -2104,25 +2098,14 @@ __device__ __forceinline__ uint32_t block_length(const uint32_t *__restrict__ in
     return uni(n_raw);
 }
 
-// ---- choosing between the two kernels: per launch by a sample (auto, the default) or per block (route)
-// The multi-wave ("dual") kernel wins on compressible data (three waves per SIMD fill each other's
-// issue slots: text +65%, low-entropy +67%), the single kernel on incompressible data (whole block in
-// registers, no slow global-table wave: +7%).  AUTO: a tiny sampling kernel decides for the whole launch
-// (below).  ROUTE (SZ_KERNEL=route): one launch may hold both kinds, so the choice is made per block,
-// inside the launch: the single kernel starts every block,
-// and the first copy it is about to follow up (chain state: the data does repeat) makes it give the
-// block up -- out_len[b] = kRoutedMarker -- at a cost of a few microseconds; the multi-wave kernel,
-// next on the stream, compresses exactly the marked blocks from scratch.  Incompressible blocks never
-// reach a copy and stay where the register-resident stream is.  No host synchronisation, no sampling
-// pass: the call stays asynchronous and graph-capturable; either kernel produces the same bytes, so
-// the routing only decides speed.  Measured (gpurun_out/r2i, 2026-10): against AUTO, ROUTE costs the
-// blocks it hands over their first microseconds and a wasted 64 KiB register stream each (c5 675 -> 564
-// GB/s, text -1 %), and an all-incompressible launch two more launches (c3 -3 %); on BASELINE.json's C4
-// mix (equal thirds) it gains nothing (141 vs 143 GB/s) because the incompressible third costs the
-// multi-wave kernel only 2 % of the launch -- what holds the mix under the harmonic mean of its parts
-// at 16 386 blocks is the tail of the persistent grid (155 GB/s at 65 536 blocks either way).  ROUTE
-// pays when a launch is mostly incompressible with a compressible minority, which AUTO sends through
-// the single kernel whole.  Hence opt-in.
+// ---- choosing between the kernels: per launch, by a sample of the data (auto, the default)
+// The persistent kernels win on compressible data (several waves per SIMD fill each other's issue slots), the single
+// kernel on incompressible data (whole block in registers, no slow global-table wave: +7 %).  A tiny sampling kernel
+// decides for the whole launch (below); every candidate kernel is enqueued and the ones not chosen exit at once: no
+// host synchronisation, graph-capturable, and a wrong guess only costs speed.  (A choice per block inside the launch --
+// the single kernel handing blocks with a copy to the multi-wave kernel, SZ_KERNEL=route in rounds 2-3 -- measured
+// slower on every workload but a compressible minority in an incompressible launch and was removed in round 4:
+// tools/patches/route_mode.patch, EXPERIMENTS.md section 4.1.2.)
 __global__ __launch_bounds__(64) void reset_launch_state_kernel(uint32_t *__restrict__ select)
 {
     if (threadIdx.x < 16)
@@ -2280,30 +2263,11 @@ __global__ __launch_bounds__(256) void place_blocks_kernel(const uint8_t *__rest
         select[3] = n_blocks;
 }
 
-// Between the two kernels (SZ_KERNEL=route): the blocks the single kernel marked, as a compact queue for the
-// multi-wave kernel's waves.  One ballot and one atomic add per wave of 64 blocks (the order of the
-// queue does not matter); select[3] = number of routed blocks.
-__global__ __launch_bounds__(256) void compact_routed_kernel(const uint32_t *__restrict__ out_len, uint32_t n_blocks,
-                                                            uint32_t *__restrict__ queue, uint32_t *__restrict__ select)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
-    const bool routed = i < n_blocks && out_len[i] == kRoutedMarker;
-    const uint64_t m = ballot64(routed);
-    if (m == 0)
-        return;
-    uint32_t base = 0;
-    if (lane == 0)
-        base = atomicAdd(&select[3], (uint32_t)__builtin_popcountll(m));
-    base = uni(base);
-    if (routed)
-        queue[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1))] = i;
-}
-
 // Single kernel: one 64-lane workgroup per block, table in LDS, whole block in registers.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void compress_blocks_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
-    uint32_t *__restrict__ out_len, uint32_t flags, uint32_t route, const uint32_t *__restrict__ select)
+    uint32_t *__restrict__ out_len, uint32_t flags, const uint32_t *__restrict__ select)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];  // the whole LDS budget: 32 KiB
     const uint32_t lane = threadIdx.x;
@@ -2319,11 +2283,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     const HashTab<true> tab{lds_tab, nullptr, nullptr};
     uint32_t op;
-    if (route)  // route mode: compressible blocks are left to the multi-wave kernel (kRoutedMarker)
-        op = compress_one_block<64, false, HashTab<true>, true>(tab, src + (uint64_t)b * in_stride, n,
-                                                                 dst + (uint64_t)b * dst_stride, flags, lane);
-    else if (select)  // auto mode, and the sample says incompressible: the instance without the fast dense path
-        op = compress_one_block<64, false, HashTab<true>, false, false>(tab, src + (uint64_t)b * in_stride, n,
+    if (select)  // auto mode, and the sample says incompressible: the instance without the fast dense path
+        op = compress_one_block<64, false, HashTab<true>, false>(tab, src + (uint64_t)b * in_stride, n,
                                                                          dst + (uint64_t)b * dst_stride, flags, lane);
     else
         op = compress_one_block<64, false>(tab, src + (uint64_t)b * in_stride, n, dst + (uint64_t)b * dst_stride,
@@ -2356,8 +2317,6 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
     __shared__ uint32_t dup_bm[(kGroupWaves - 1) * 512];  // one 16384-bit bitmap per global-table wave
     if ((auto_mode & 1u) && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
         return;
-    // route mode (queue != nullptr): the blocks of this launch's queue, filled behind the single kernel
-    // (an all-incompressible launch leaves it empty: every workgroup is gone before it does anything)
     if ((auto_mode & 2u) && (auto_mode & 1u) && !launch_is_mixed(select))
         queue = nullptr;  // an order queue, and the sample found one kind of block only: it was not filled
     const uint32_t n_work = queue ? uni(select[3]) : n_blocks;
@@ -2577,7 +2536,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
 #endif
         const uint8_t *in_b = reinterpret_cast<const uint8_t *>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
         uint8_t *out_b = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
-        const uint32_t op = compress_one_block<0, true, HashTab<true>, false, true, SZ_MATCH_PIECES, WaveTeam<kTeamWaves>>(
+        const uint32_t op = compress_one_block<0, true, HashTab<true>, true, SZ_MATCH_PIECES, WaveTeam<kTeamWaves>>(
             tab, in_b, n, out_b, uni(a->flags), lane, team);
         if (op != kTeamNotMine) {
             // (a9) the wave that finished the block, or the first wave that gave it up: every lane, same address, same value
@@ -2617,7 +2576,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
         return;
     const HashTab<true> tab{dyn_tab, nullptr, nullptr};
     // (1 KiB steps of match extension: the blocks are small and the kernel runs four waves per SIMD)
-    const uint32_t op = compress_one_block<0, true, HashTab<true>, false, true, 1>(tab, src + (uint64_t)b * block_bytes, block_bytes,
+    const uint32_t op = compress_one_block<0, true, HashTab<true>, true, 1>(tab, src + (uint64_t)b * block_bytes, block_bytes,
                                                     dst + (uint64_t)b * dst_stride, flags, lane);
     out_len[b] = op;  // (a9) every lane, same address, same value
 }
@@ -2653,7 +2612,6 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
         return hipGetLastError();
     }
     const bool dual_ok = dual && dual->tables && n_blocks >= dual->min_blocks;
-    const bool route = dual_ok && dual->mode == kDualRoute && dual->queue && n_blocks <= dual->queue_cap;
     const bool sampled = dual_ok && dual->mode == kDualAuto;
     if (dual_ok)  // launch state := 0.  (A kernel, not hipMemsetAsync: captured into a hipGraph, the
                   // memset node made every replay after the first a no-op.)
@@ -2664,22 +2622,17 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
         hipLaunchKernelGGL(sample_compressibility_kernel, dim3(ns), dim3(256), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dual->select);
     }
-    // route mode: the single kernel starts every block and leaves the compressible ones, marked in
-    // out_len, to the multi-wave kernel behind it on the stream (no host sync either)
-    if (!dual_ok || sampled || route) {
+    if (!dual_ok || sampled) {
         if (prof.single0)
             (void)hipEventRecord(prof.single0, stream);
         hipLaunchKernelGGL(compress_blocks_kernel, dim3(n_blocks), dim3(64), 0, stream, src, in_stride, d_in_len,
-                               total_len, n_blocks, dst, dst_stride, d_out_len, flags, route ? 1u : 0u,
+                               total_len, n_blocks, dst, dst_stride, d_out_len, flags,
                                sampled ? dual->select : (const uint32_t *)nullptr);
         if (prof.single1)
             (void)hipEventRecord(prof.single1, stream);
     }
-    if (route)
-        hipLaunchKernelGGL(compact_routed_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, stream, d_out_len, n_blocks,
-                           dual->queue, dual->select);
-    // longest blocks first: the queue of the persistent kernel in cost order (not with route, which has a queue of its own)
-    const bool ordered = dual_ok && !route && dual->queue && n_blocks >= 256 && 2ull * n_blocks <= dual->queue_cap;
+    // longest blocks first: the queue of the persistent kernel in cost order
+    const bool ordered = dual_ok && dual->queue && n_blocks >= 256 && 2ull * n_blocks <= dual->queue_cap;
     if (ordered) {
         uint8_t *cls = reinterpret_cast<uint8_t *>(dual->queue + dual->queue_cap / 2);
         const uint32_t cgrid = (n_blocks + 3) / 4 < 2048u ? (n_blocks + 3) / 4 : 2048u;
@@ -2689,7 +2642,7 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
         hipLaunchKernelGGL(place_blocks_kernel, dim3(pgrid), dim3(256), 0, stream, cls, n_blocks,
                            dual->queue, dual->select, sampled ? 1u : 0u);
     }
-    const uint32_t *work_queue = (route || ordered) ? dual->queue : (const uint32_t *)nullptr;
+    const uint32_t *work_queue = ordered ? dual->queue : (const uint32_t *)nullptr;
     if (dual_ok) {
         // enough blocks to keep kGroupWaves waves per SIMD busy on every CU: persistent grid
         if (dual->kernel == kKernelTeam) {

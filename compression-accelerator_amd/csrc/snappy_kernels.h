@@ -11,16 +11,16 @@ constexpr int32_t kStatusCorrupt = -74;    // == SZ_ECORRUPT
 constexpr int32_t kStatusNoSpace = -28;    // == SZ_ENOSPC
 
 // Workspace of the multi-wave kernel: n_slots x (waves - 1) hash tables of 16384 x uint16 (zeroed by
-// their wave per block), the launch state and the routed-block queue; one launch sequence at a time.
-enum DualMode : uint32_t { kDualAuto = 0, kDualRoute = 1, kDualAlways = 2 };
+// their wave per block), the launch state and the block queue (cost order); one launch sequence at a time.
+enum DualMode : uint32_t { kDualAuto = 0, kDualAlways = 2 };
 struct DualScratch {
     uint16_t *tables;
-    uint32_t *select;     // launch state: [0] repeats, [1] positions of the sample; [2] next entry of the block queue, [3] number of routed blocks
-    uint32_t *queue;      // indices of the blocks routed to the multi-wave kernel (auto mode)
-    uint32_t queue_cap;   // entries in `queue`; launches with more blocks are not routed
+    uint32_t *select;     // launch state: [0] repeats, [1] positions of the sample; [2] next entry of the block queue, [3] number of blocks in the queue
+    uint32_t *queue;      // block indices in cost order for the persistent kernels (+ one class byte per block in its upper half)
+    uint32_t queue_cap;   // entries in `queue`; launches with more than half as many blocks are not ordered
     uint32_t n_slots;
     uint32_t min_blocks;  // launches with fewer blocks use the single kernel
-    uint32_t mode;        // kDualAuto: single/dual per launch from a data sample; kDualRoute: per block
+    uint32_t mode;        // kDualAuto: single kernel or persistent kernel per launch, from a data sample; kDualAlways: the persistent kernel
     uint32_t kernel;      // which kernel takes the compressible launches: kKernelMulti or kKernelTeam
 };
 enum CompressibleKernel : uint32_t { kKernelMulti = 0, kKernelTeam = 1 };

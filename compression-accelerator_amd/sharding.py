@@ -18,8 +18,7 @@ def shard_range(n_blocks_total, rank, world):
 
 def check_lengths(lens, slot_stride=None):
     """Raises if a per-block length is one of the kernels' markers (0xffffffff: block longer than 64 KiB;
-    0xfffffffe: poisoned result; 0xfffffffd: SZ_KERNEL=route's "handed to the multi-wave kernel", never left
-    behind by a finished launch), which read as negative int32, or exceeds the slot stride.
+    0xfffffffe: poisoned result), which read as negative int32, or exceeds the slot stride.
     One device synchronisation: call it where the lengths are consumed, not inside a timed loop."""
     bad = lens < 0
     if slot_stride is not None:

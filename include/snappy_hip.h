@@ -38,8 +38,8 @@
  *   SZ_KERNEL  forces a compress kernel: `single` (one wave per block, table in LDS: what incompressible
  *              launches get), `team` (two waves share a block and its LDS table + two waves per workgroup
  *              with tables in global memory: what compressible launches get), `dual` (rounds 1-2's kernel
- *              for compressible launches: three independent waves per workgroup; kept for comparison),
- *              `route` (per block inside the launch: the single kernel hands blocks with a copy to `dual`).
+ *              for compressible launches: three independent waves per workgroup; kept as a second
+ *              implementation for differential tests and A/B).
  *              Unset: the sampled choice between `single` and `team`.
  *   SZ_DECODE_KERNEL  forces a decode kernel: `single` (one wave per stream), `pair` (two:
  *              one parses the next window while the other moves this one's bytes).  Unset: `pair` for launches
