@@ -609,18 +609,14 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         // shuffles (ds_bpermute: LDS crossbar, no memory access) and v_alignbyte.
         const uint32_t last16 = n - 16;  // n >= 15 here; (n == 15: no position is probed at all)
         // An empty bucket reads as position 0 (as in the reference), so a probe whose bucket is empty is compared with
-        // the block's first bytes: they are kept in registers (general code of the instances that have registers to
-        // spare), and a batch of probes in which NO lane has a real candidate -- every batch of an incompressible
-        // block -- then does without the candidate loads, i.e. without a memory round trip of its own (an
-        // incompressible 64 KiB block had 7 dependent round trips, ~3 us each under load; about two are left: C3 +2 %,
-        // EXPERIMENTS.md R4.2).
-        constexpr bool kZeroCand = !kLean;
-        const bool zok = kZeroCand && n >= 64;
-        u32x4 z0 = {0, 0, 0, 0}, z1 = {0, 0, 0, 0};
-        if (zok) {
-            z0 = ld128(in);
-            z1 = ld128(in + 16);
-        }
+        // the block's first four bytes: they are kept in a scalar register, and a batch of probes in which no lane has
+        // a real candidate and no lane's shingle equals them -- every batch of an incompressible block -- does without
+        // its candidate loads, i.e. without a memory round trip of its own (an incompressible 64 KiB block had 7
+        // dependent round trips, ~3 us each under load; about two are left: C3 +2 %, EXPERIMENTS.md R4.2).
+        const bool zok = n >= 64;
+        uint32_t z0x = 0;
+        if (zok)
+            z0x = uni(ld32(in));
         u32x4 a = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
         uint32_t wcur = 0, wnxt = 0, wnxt_sh = 0, kcur = 0;  // buffers kcur and kcur + 1
         // (the prefetched buffer stays as loaded until it becomes the current one: the shift that puts
@@ -1668,8 +1664,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 const uint32_t nvalid = ip_limit - W0 < 63 ? ip_limit - W0 : 63;  // W0 < ip_limit
                 PROF_LAPV(1);
                 // candidates' bytes: unpredicated (cand < pos <= n-16, or 0 for lanes without one)
-                u32x4 c = z0, c2 = z1;  // (n >= 64: last16 > 16, the second load of a lane with cand == 0 is bytes 16..31)
-                if (!zok || __ballot(cand != 0) != 0) {
+                u32x4 c = {~a.x, 0, 0, 0}, c2 = {0, 0, 0, 0};  // (no load: no lane hits)
+                if (!zok || __ballot(cand != 0 || (spec && a.x == z0x)) != 0) {
                     c = ld128(in + cand);
                     c2 = ld128(in + (cand + 16 < last16 ? cand + 16 : last16));
                 }
@@ -2007,8 +2003,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             }
             const uint32_t nact = nvalid < cut ? nvalid : cut;
             const bool act = lane < nact;
-            u32x4 c = z0;
-            if (!zok || __ballot(act && cand != 0) != 0) {
+            u32x4 c = {~v, 0, 0, 0};  // (no load: no lane hits)
+            if (!zok || __ballot(act && (cand != 0 || v == z0x)) != 0) {
                 c = u32x4{0, 0, 0, 0};
                 if (act)
                     c = ld128(in + cand);  // cand < p <= n-16: in bounds
