@@ -113,3 +113,32 @@ def test_large_launch_with_unaligned_bases():
     """Enough blocks for the sampled choice and the persistent kernels (2 x 4 x CUs and more), bases off by 9 and 7."""
     blocks = _blocks(64, 5)
     _run(blocks * 36, 9, 7, BLOCK, 76501)
+
+
+def test_profile_events_bracket_the_dominant_kernel_once(kernel_mode):
+    """sz_profile_next_launch (include/snappy_hip.h): the events handed over are recorded around the kernel that does
+    the work of the NEXT launch of this thread -- and of that launch only."""
+    import sys
+    import torch
+    from build_util import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    P = pkg()
+    nb = 2304  # (enough blocks for the sampled choice and the persistent kernels)
+    src = bench.make_input("text", 0, nb, torch.device("cuda:0"))
+    hev = bench.HipEvents(2)
+    try:
+        multi = kernel_mode != "single"  # text: the sample sends it to the persistent kernel unless one is forced
+        four = hev.ev[0]
+        P.profile_next_launch(four[0], four[1], four[2], four[3])
+        dst, ol = P.compress_blocks(src, BLOCK, nb)
+        P.compress_blocks(src, BLOCK, nb, dst=dst, out_len=ol)  # (one shot: this launch records nothing)
+        torch.cuda.synchronize()
+        t = hev.ms(0, multi)
+        assert t is not None and 0.05 < t < 50.0, t  # the kernel that compressed 144 MiB of text
+        if kernel_mode == "auto":  # both were enqueued; the one not chosen exits at once
+            other = hev.ms(0, not multi)
+            assert other is not None and other < t / 4, (other, t)
+        assert hev.ms(1, multi) is None  # never handed to the library: never recorded
+    finally:
+        hev.close()
