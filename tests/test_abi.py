@@ -21,6 +21,27 @@ def _declared_symbols():
     return sorted(set(re.findall(r"\b((?:sz_|rocc_)[a-z0-9_]+)\s*\(", hdr)))
 
 
+def test_jni_shim_uses_only_the_declared_abi():
+    """compression-accelerator_amd/drivers/jni/ (the north star's Scala/JVM driver) cannot be compiled here -- no JDK,
+    no jni.h --, so at least its contact with the library is pinned: every sz_* function the shim calls and every
+    SZ_* constant it names is declared in include/snappy_hip.h, every native method of SnappyHip.scala has its
+    Java_snappyhip_SnappyHip_00024_<name> in the shim and the other way round."""
+    jdir = os.path.join(ROOT, "compression-accelerator_amd", "drivers", "jni")
+    c = open(os.path.join(jdir, "snappy_hip_jni.c")).read()
+    c = re.sub(r"/\*.*?\*/", "", c, flags=re.S)
+    hdr = open(os.path.join(ROOT, "include", "snappy_hip.h")).read()
+    declared = set(_declared_symbols())
+    used = set(re.findall(r"\b(sz_[a-z0-9_]+)\s*\(", c))
+    assert used and used <= declared, used - declared
+    consts = set(re.findall(r"\b(SZ_[A-Z0-9_]+)\b", c))
+    defined = set(re.findall(r"#define\s+(SZ_[A-Z0-9_]+)\b", hdr))
+    assert consts <= defined, consts - defined
+    scala = open(os.path.join(jdir, "SnappyHip.scala")).read()
+    natives = set(re.findall(r"@native\s+def\s+(\w+)", scala))
+    shims = set(re.findall(r"Java_snappyhip_SnappyHip_00024_(\w+)\s*\(", c))
+    assert natives == shims and len(natives) >= 4, natives ^ shims
+
+
 def test_library_exports_every_declared_symbol():
     P = load_package()
     L = ctypes.CDLL(P.LIB_PATH)
