@@ -493,6 +493,11 @@ def _time_libsnappy(lib, src, sample_blocks, cores, budget_s):
 # ----------------------------------------------------------------------------------------- one rank
 
 def rank_main(args):
+    # ONE line on stdout: the JSON.  Libraries that write to file descriptor 1 on their own (RCCL prints a five-line
+    # version banner at its first collective) are sent to stderr; the line itself goes to the descriptor kept here.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -610,7 +615,8 @@ def rank_main(args):
                     extras[kind]["cpu_baseline"] = {k: t[k] for k in ("value", "unit", "cores", "kind", "single_thread_GBps", "sample")}
                     if "system_libsnappy" in t:
                         extras[kind]["cpu_baseline"]["system_libsnappy"] = t["system_libsnappy"]
-        print(json.dumps(line), flush=True)
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
