@@ -200,6 +200,7 @@ struct Workspace {
     void *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[5] = {0, 0, 0, 0, 0};
     int device = -1;
+    std::vector<uint8_t> host;  // staging of the one-fragment path (slot + length in one copy)
 
     int ensure_stream()
     {
@@ -513,6 +514,34 @@ int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *ou
     int rc = ws.ensure_stream();
     if (rc)
         return rc;
+    if (n <= SZ_BLOCK_SIZE) {
+        // One fragment (what the RoCC surface sends: one buffer per COMPRESS command, 130 bytes in tests/compression.c):
+        // the block's own raw stream -- varint + body, SZ_FLAG_BLOCK_VARINT -- IS snappy::Compress's output, so there is
+        // nothing to pack, and length and bytes come back in ONE copy behind ONE synchronisation (the length sits right
+        // behind the slot): 67 -> ~40 us for 130 bytes against the general path below (two more kernels, a copy and a
+        // synchronisation for the length alone).
+        const size_t bound = (sz_max_compressed_length(n) + 5 + 15) & ~(size_t)15;  // slot, and the offset of the length behind it
+        if ((rc = ws.reserve(0, n)) || (rc = ws.reserve(1, bound + 16)))
+            return rc;
+        uint8_t *d_in = static_cast<uint8_t *>(ws.buf[0]);
+        uint8_t *d_slot = static_cast<uint8_t *>(ws.buf[1]);
+        ws.host.resize(bound + 16);
+        SZ_HIP(hipMemcpyAsync(d_in, src, n, hipMemcpyHostToDevice, ws.stream));
+        if ((rc = sz_compress_blocks_hip(d_in, n, nullptr, 1, d_slot, bound, reinterpret_cast<uint32_t *>(d_slot + bound),
+                                         SZ_FLAG_BLOCK_VARINT, ws.stream)))
+            return rc;
+        SZ_HIP(hipMemcpyAsync(ws.host.data(), d_slot, bound + 4, hipMemcpyDeviceToHost, ws.stream));
+        SZ_HIP(hipStreamSynchronize(ws.stream));
+        uint32_t len = 0;
+        memcpy(&len, ws.host.data() + bound, sizeof(len));
+        if (len > bound)  // an error marker instead of a length
+            return SZ_EHIP;
+        if (len > dst_cap)
+            return SZ_ENOSPC;
+        memcpy(dst, ws.host.data(), len);  // (the varint it starts with is the one written above)
+        *out_len = len;
+        return SZ_OK;
+    }
     const uint32_t nb = (uint32_t)((n + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
     const size_t stride = SZ_SLOT_STRIDE;
     if ((rc = ws.reserve(0, n)) || (rc = ws.reserve(1, (size_t)nb * stride)) ||
@@ -595,6 +624,32 @@ int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *
     }
     uint32_t meta[3] = {(uint32_t)n, 0, 0};
     SZ_HIP(hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, ws.stream));
+    if (ulen <= SZ_BLOCK_SIZE) {
+        // One fragment (the RoCC surface's UNCOMPRESS of what one COMPRESS wrote): decoded size, status and bytes come
+        // back in ONE copy behind ONE synchronisation -- the two words sit right behind the output --, and `dst` is
+        // written only when the stream was good.
+        const size_t tail = (ulen + 15) & ~(size_t)15;
+        if ((rc = ws.reserve(1, tail + 16)))
+            return rc;
+        d_out = static_cast<uint8_t *>(ws.buf[1]);
+        uint32_t *d_res = reinterpret_cast<uint32_t *>(d_out + tail);  // [0] = decoded size, [1] = status
+        if ((rc = sz_uncompress_blocks_hip(d_in, n, d_meta, 1, d_out, ulen, d_res, reinterpret_cast<int32_t *>(d_res + 1),
+                                           ws.stream)))
+            return rc;
+        ws.host.resize(tail + 8);
+        SZ_HIP(hipMemcpyAsync(ws.host.data(), d_out, tail + 8, hipMemcpyDeviceToHost, ws.stream));
+        SZ_HIP(hipStreamSynchronize(ws.stream));
+        uint32_t res[2];
+        memcpy(res, ws.host.data() + tail, sizeof(res));
+        if ((int32_t)res[1] != 0)
+            return (int32_t)res[1];
+        if (res[0] != ulen)
+            return SZ_ECORRUPT;
+        if (ulen)
+            memcpy(dst, ws.host.data(), ulen);
+        *out_len = ulen;
+        return SZ_OK;
+    }
     if ((rc = sz_uncompress_blocks_hip(d_in, n, d_meta, 1, d_out, ulen, d_meta + 1,
                                        reinterpret_cast<int32_t *>(d_meta + 2), ws.stream)))
         return rc;
