@@ -614,9 +614,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         // its candidate loads, i.e. without a memory round trip of its own (an incompressible 64 KiB block had 7
         // dependent round trips, ~3 us each under load; about two are left: C3 +2 %, EXPERIMENTS.md R4.2).
         const bool zok = n >= 64;
-        uint32_t z0x = 0;
+        uint32_t z0v = 0;  // (every lane the same four bytes; brought to a scalar register where it is used: a
+                           // readfirstlane right here would make the wave wait for the load before it requests the block)
         if (zok)
-            z0x = uni(ld32(in));
+            z0v = ld32(in);
         u32x4 a = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
         uint32_t wcur = 0, wnxt = 0, wnxt_sh = 0, kcur = 0;  // buffers kcur and kcur + 1
         // (the prefetched buffer stays as loaded until it becomes the current one: the shift that puts
@@ -663,6 +664,11 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         };
         if (kTeamW > 1 && !holder) {
             kcur = 0xfffffffeu;  // no buffer yet: the first head of this wave loads its own
+        } else if (n >= 512) {
+            // (buffer 0 lies inside the block: no shift, so nothing here uses the loaded value -- `load_buf` would,
+            // and the wave would wait a round trip for it before it requests the block)
+            wcur = ld32(in + 4u * lane);
+            wnxt = fetch_buf(1, wnxt_sh);
         } else if (n >= 16) {
             wcur = load_buf(0);
             wnxt = fetch_buf(1, wnxt_sh);
@@ -694,6 +700,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         }
         const uint32_t blk_op = op;  // the literal must start here for the prediction to hold
 
+        // (BEHIND the block stream, and behind the wait for it: the same five gathers requested AHEAD of the stream cost
+        // 27 % of the incompressible rate, twice measured -- each touches up to ten pages that nothing has touched yet,
+        // and the stream queues behind their address translation; behind it they hit translated pages and lines in the L2)
         if (!kLean) {
             if (lane < 32 && 1 + Pn0b <= ip_limit) pv0b = ld32(in + 1 + Pr0b);
             if (1 + Pn1 <= ip_limit) pv1 = ld32(in + 1 + Pr1);
@@ -1665,7 +1674,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 PROF_LAPV(1);
                 // candidates' bytes: unpredicated (cand < pos <= n-16, or 0 for lanes without one)
                 u32x4 c = {~a.x, 0, 0, 0}, c2 = {0, 0, 0, 0};  // (no load: no lane hits)
-                if (!zok || __ballot(cand != 0 || (spec && a.x == z0x)) != 0) {
+                if (!zok || __ballot(cand != 0 || (spec && a.x == uni(z0v))) != 0) {
                     c = ld128(in + cand);
                     c2 = ld128(in + (cand + 16 < last16 ? cand + 16 : last16));
                 }
@@ -2004,7 +2013,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             const uint32_t nact = nvalid < cut ? nvalid : cut;
             const bool act = lane < nact;
             u32x4 c = {~v, 0, 0, 0};  // (no load: no lane hits)
-            if (!zok || __ballot(act && (cand != 0 || v == z0x)) != 0) {
+            if (!zok || __ballot(act && (cand != 0 || v == uni(z0v))) != 0) {
                 c = u32x4{0, 0, 0, 0};
                 if (act)
                     c = ld128(in + cand);  // cand < p <= n-16: in bounds
