@@ -81,6 +81,17 @@ __device__ unsigned long long g_prof[160];  // [128,160): phases of match_length
 #define ML_START() do { } while (0)
 #define ML_LAP(i) do { } while (0)
 #endif
+#if defined(SZ_PE) || defined(SZ_PROF)
+__device__ unsigned long long g_pe[65536 * 4];
+#endif
+#if defined(SZ_PE) || defined(SZ_PROF)
+// block phases (tools/c3prof.hip): 28 entry -> stream requested, 29 -> main loop, 30 main loop, 31 -> return; s_memtime (shader clock)
+#define PE_START() unsigned long long pe_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pe_) :: "memory")
+#define PE_LAP(i) do { unsigned long long t2_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); if (lane == 0) g_pe[(blockIdx.x & 0xffffu) * 4u + ((i) - 28)] = t2_ - pe_; pe_ = t2_; } while (0)  // (one slot per block and phase: plain stores, nothing shared)
+#else
+#define PE_START() do { } while (0)
+#define PE_LAP(i) do { } while (0)
+#endif
 
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxTable = 16384u;
@@ -555,6 +566,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
                                                        uint32_t lane, const TeamT &team = TeamT{})
 {
+    PE_START();
     constexpr int kTeamW = TeamT::kWaves;  // 1: this wave compresses the block alone
     // team mode: wave 0 starts the block (it holds the parse token of turn 0 and the output position);
     // the others wait for a token.  Blocks too short for the fast dense path are wave 0's alone.
@@ -699,6 +711,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             }
         }
         const uint32_t blk_op = op;  // the literal must start here for the prediction to hold
+        PE_LAP(28);
 
         // (BEHIND the block stream, and behind the wait for it: the same five gathers requested AHEAD of the stream cost
         // 27 % of the incompressible rate, twice measured -- each touches up to ten pages that nothing has touched yet,
@@ -784,6 +797,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         uint32_t sc = 0;         // scan: index of the next probe
         uint32_t scan_base = 1;  // scan: position of probe 0 (skip == 32 there)
         bool first_scan = !kLean;  // pv[] belongs to the scan that starts at 1
+        PE_LAP(29);
         PROF_DECL
         PROF_START();
         // (every trip of this loop moves P forward or ends it; the cap turns a state that does neither
@@ -2051,6 +2065,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             PROF_LAP(7);
         }
         PROF_FLUSH();
+        PE_LAP(30);
         if constexpr (kTeamW > 1) {
             if (team_gone)  // another wave finishes (or finished) the block; a lost wave says so
                 return team_lost ? kTeamLost : kTeamNotMine;
@@ -2085,6 +2100,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         if (n >= 1024)  // the waves that wait for a token leave
             team_publish(team.ptok, (uint64_t)kTeamDoneTurn << 42);
     }
+    PE_LAP(31);
     return poisoned ? 0xfffffffeu : op;
 }
 
