@@ -389,7 +389,8 @@ template <bool in_lds>
 struct HashTab {
     uint16_t *lds;
     uint16_t *glob;
-    uint32_t *bm;  // global home only: 16384-bit scratch bitmap in LDS (all zero between uses)
+    uint32_t *bm;   // global home only: 8192-bit scratch bitmap in LDS (all zero between uses), over 13 bits of the bucket number
+    uint32_t *occ;  // global home only: 16384-bit bitmap in LDS, bit h = bucket h has been written in THIS block
     static constexpr bool kInLds = in_lds;
 
     // (relaxed atomics = plain loads/stores that the compiler may neither forward nor merge: other
@@ -399,33 +400,51 @@ struct HashTab {
     // wave's stores (write-through) and loads of one address reach the L2 in issue order.  Measured
     // against the wave-scope load: no difference in rate (these lines miss the L1 anyway: 8 x 32 KiB of
     // tables per CU).  tests/test_abi.py checks the instruction.)
+    // Global home (round 5): a bucket nobody has written in this block is EMPTY -- it reads as position 0, as in
+    // the reference -- and which buckets have been written is kept in 2 KiB of LDS (`occ`).  A look-up goes to the
+    // table in memory only for the lanes whose bucket is occupied (a tile of text looks up 64 positions of which
+    // ~14 are probed; a third to a half of them find an empty bucket: that many fewer 64-byte reads over the fabric,
+    // where every look-up of these tables is a miss in the L2), and the table in memory is never cleared: what an
+    // earlier block left in a bucket is not read before this block has written the bucket.
     __device__ __forceinline__ uint32_t get(uint32_t h) const
     {
         if (in_lds)
             return __hip_atomic_load(lds + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        return __hip_atomic_load(glob + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t w = __hip_atomic_load(occ + (h >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        uint32_t v = 0;
+        if ((w >> (h & 31u)) & 1u)
+            v = __hip_atomic_load(glob + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
     }
     __device__ __forceinline__ void put(uint32_t h, uint32_t v) const
     {
-        if (in_lds)
+        if (in_lds) {
             __hip_atomic_store(lds + h, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        else
+        } else {
             __hip_atomic_store(glob + h, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_or(occ + (h >> 5), 1u << (h & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
     }
     // (a2) table of T = 2^log2T entries, all empty
     __device__ __forceinline__ void clear(uint32_t log2T, uint32_t lane) const
     {
-        const uint32_t nvec = (1u << log2T) >> 3;  // 16-byte chunks
         u32x4 z = {0, 0, 0, 0};
         if (in_lds) {
+            const uint32_t nvec = (1u << log2T) >> 3;  // 16-byte chunks
             for (uint32_t i = lane; i < nvec; i += 64)
                 reinterpret_cast<u32x4 *>(lds)[i] = z;
         } else {
-            for (uint32_t i = lane; i < nvec; i += 64)
-                reinterpret_cast<u32x4 *>(glob)[i] = z;
+            reinterpret_cast<u32x4 *>(occ)[lane] = z;  // 2 KiB: no bucket is occupied
+            reinterpret_cast<u32x4 *>(occ)[64 + lane] = z;
         }
     }
+    // global home: the scratch bitmap's word and bit of bucket h (13 of its 14 bits: two buckets share a bit, and a
+    // lane that finds its bit set by the other bucket is told apart by the full hashes where the cut is worked out)
+    __device__ __forceinline__ uint32_t *bm_word(uint32_t h) const { return bm + ((h & 8191u) >> 5); }
 };
+static constexpr uint32_t kGlobBmWords = 256;   // scratch bitmap of a global-table wave: 8192 bits
+static constexpr uint32_t kGlobOccWords = 512;  // occupancy bitmap: 16384 bits
+static constexpr uint32_t kGlobLdsWords = kGlobBmWords + kGlobOccWords;  // per global-table wave: 3 KiB of LDS
 
 // ------------------------------------------------------------------------ wave teams
 //
@@ -1599,9 +1618,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                 const uint32_t bit = 1u << (th & 31u);
                                 uint32_t old = 0;
                                 if (inC)
-                                    old = __hip_atomic_fetch_or(tab.bm + (th >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                    old = __hip_atomic_fetch_or(tab.bm_word(th), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                                 if (inC)
-                                    __hip_atomic_store(tab.bm + (th >> 5), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                    __hip_atomic_store(tab.bm_word(th), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                                 L = ballot64(inC && (old & bit) != 0);
                             }
                             if (__builtin_expect(L != 0, 0)) {  // two inserted lanes share a bucket: end the visit before the second one
@@ -1616,14 +1635,17 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                     const uint64_t G = ballot64(inC && th == hv);
                                     L &= ~G;
                                     const uint64_t G2 = G & (G - 1);
-                                    const uint32_t second = ctz64(G2);
+                                    const uint32_t second = G2 ? ctz64(G2) : 64u;  // (global home: a lane alone in G shared its BIT with another bucket)
                                     cut = second < cut ? second : cut;
                                 }
-                                // (cut <= e or no cut at all cannot happen: a lost write that no shared
-                                // bucket explains.  The block is poisoned instead of looping on it.)
-                                const bool bad_cut = cut <= e || cut >= 64;
+                                // (cut <= e, or with the table in LDS no cut at all, cannot happen: a lost write that no
+                                // shared bucket explains.  The block is poisoned instead of looping on it.  Global home: no
+                                // cut at all = only bits of the scratch bitmap were shared, no bucket: the visit stands.)
+                                const bool no_cut = !Tab::kInLds && cut >= 64;
+                                const bool bad_cut = !no_cut && (cut <= e || cut >= 64);
                                 poisoned = poisoned || bad_cut;
-                                exit_for(bad_cut ? e + 1 : cut);
+                                if (!no_cut)
+                                    exit_for(bad_cut ? e + 1 : cut);
                                 if (__builtin_amdgcn_inverse_ballot_w64(C))
                                     tab.put(th, pos);  // lanes below a cut share no bucket
                                 UNIFORM_JOIN();
@@ -1857,10 +1879,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         const uint32_t bit = 1u << (h & 31u);
                         uint32_t old = 0;
                         if (ins_lane)
-                            old = __hip_atomic_fetch_or(tab.bm + (h >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            old = __hip_atomic_fetch_or(tab.bm_word(h), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         L = __ballot(ins_lane && (old & bit));
                         if (ins_lane)
-                            __hip_atomic_store(tab.bm + (h >> 5), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            __hip_atomic_store(tab.bm_word(h), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         PROF_LAPV(9);
                         if (L == 0) {
                             if (ins_lane)
@@ -1875,8 +1897,16 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         const uint64_t G = __ballot(ins_lane && h == hv);
                         L &= ~G;
                         const uint64_t G2 = G & (G - 1);
-                        const uint32_t second = ctz64(G2);
+                        const uint32_t second = G2 ? ctz64(G2) : 64u;  // (global home: a lane alone in G shared its BIT with another bucket)
                         cut = second < cut ? second : cut;
+                    }
+                    if constexpr (!Tab::kInLds) {
+                        if (cut >= 64) {  // only bits of the scratch bitmap were shared, no bucket: the path is final
+                            if (ins_lane)
+                                tab.put(h, pos);
+                            UNIFORM_JOIN();
+                            break;
+                        }
                     }
                     // (a lost write that no shared bucket explains would repeat forever: with an LDS
                     // table it cannot happen; with a global-memory table it would mean this wave's
@@ -2302,7 +2332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         out_len[b] = 0xffffffffu;  // (every lane, same address, same value: see the note at the dual kernel)
         return;
     }
-    const HashTab<true> tab{lds_tab, nullptr, nullptr};
+    const HashTab<true> tab{lds_tab, nullptr, nullptr, nullptr};
     uint32_t op;
     if (select)  // auto mode, and the sample says incompressible: the instance without the fast dense path
         op = compress_one_block<64, false, HashTab<true>, false>(tab, src + (uint64_t)b * in_stride, n,
@@ -2335,7 +2365,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
     uint32_t *__restrict__ select, const uint32_t *__restrict__ queue, uint32_t auto_mode)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
-    __shared__ uint32_t dup_bm[(kGroupWaves - 1) * 512];  // one 16384-bit bitmap per global-table wave
+    __shared__ __attribute__((aligned(16))) uint32_t dup_bm[(kGroupWaves - 1) * kGlobLdsWords];  // per global-table wave: scratch bitmap + occupancy bitmap
     if ((auto_mode & 1u) && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
         return;
     if ((auto_mode & 2u) && (auto_mode & 1u) && !launch_is_mixed(select))
@@ -2346,8 +2376,8 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     if (wave >= 1)
-        for (uint32_t i = lane; i < 512; i += 64)
-            dup_bm[(wave - 1) * 512u + i] = 0;
+        for (uint32_t i = lane; i < kGlobLdsWords; i += 64)
+            dup_bm[(wave - 1) * kGlobLdsWords + i] = 0;
     const uint32_t my_slot = blockIdx.x * (kGroupWaves - 1) + (wave ? wave - 1 : 0);
     uint16_t *my_glob = scratch_tables + (size_t)my_slot * kMaxTable;
     // The waves whose table is in LDS go first at the issue port: they wait least (no table access
@@ -2380,11 +2410,11 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
         }
         uint32_t op;
         if (wave >= 1) {
-            const HashTab<false> tab{nullptr, my_glob, dup_bm + (wave - 1) * 512u};
+            const HashTab<false> tab{nullptr, my_glob, dup_bm + (wave - 1) * kGlobLdsWords + kGlobOccWords, dup_bm + (wave - 1) * kGlobLdsWords};
             op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
         } else {
-            const HashTab<true> tab{lds_tab, nullptr, nullptr};
+            const HashTab<true> tab{lds_tab, nullptr, nullptr, nullptr};
             op = compress_one_block<kDualChunks, kDualLean>(tab, src + (uint64_t)b * in_stride, n,
                                                             dst + (uint64_t)b * dst_stride, flags, lane);
         }
@@ -2435,7 +2465,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
     __shared__ __attribute__((aligned(16))) uint64_t tokens[2];
     __shared__ __attribute__((aligned(16))) uint8_t dup_scr[kTeamWaves * 256];
-    __shared__ uint32_t lone_bm[(kLoneWaves > 0 ? kLoneWaves : 1) * 512];  // one 16384-bit bitmap per global-table wave
+    __shared__ __attribute__((aligned(16))) uint32_t lone_bm[(kLoneWaves > 0 ? kLoneWaves : 1) * kGlobLdsWords];  // per global-table wave: scratch bitmap + occupancy bitmap
     __shared__ uint32_t next_block, team_bar, team_dead, len_claim;
     (void)args_in_kernarg;
     using KArgs = const __attribute__((address_space(4))) TeamArgs;
@@ -2478,8 +2508,8 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
     if (kLoneWaves > 0 && wave >= kTeamWaves) {
         // ---- a lone wave: blocks of its own, table in global memory (as the multi-wave kernel's extra waves)
         const uint32_t lw = wave - kTeamWaves;
-        for (uint32_t i = lane; i < 512; i += 64)
-            lone_bm[lw * 512u + i] = 0;
+        for (uint32_t i = lane; i < kGlobLdsWords; i += 64)
+            lone_bm[lw * kGlobLdsWords + i] = 0;
         for (;;) {
             uint32_t b = next_index();
             if (b >= n_work)
@@ -2495,7 +2525,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             }
             uint16_t *my_glob = reinterpret_cast<uint16_t *>(uni64((uint64_t)(uintptr_t)a->scratch_tables)) +
                                 (size_t)(blockIdx.x * (kLoneWaves > 0 ? kLoneWaves : 1) + lw) * kMaxTable;
-            const HashTab<false> gtab{nullptr, my_glob, lone_bm + lw * 512u};
+            const HashTab<false> gtab{nullptr, my_glob, lone_bm + lw * kGlobLdsWords + kGlobOccWords, lone_bm + lw * kGlobLdsWords};
             const uint8_t *in_b = reinterpret_cast<const uint8_t *>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
             uint8_t *out_b = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
             const uint32_t op = compress_one_block<0, true>(gtab, in_b, n, out_b, uni(a->flags), lane);
@@ -2512,7 +2542,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
         }
         return;
     }
-    const HashTab<true> tab{lds_tab, nullptr, nullptr};
+    const HashTab<true> tab{lds_tab, nullptr, nullptr, nullptr};
     WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr, dup_scr + wave * 256u, &team_bar};
     __builtin_amdgcn_s_setprio(SZ_TEAM_BASE_PRIO);  // (a team's waves go before the lone ones; the token's holder before both)
     // Giving up (a wave of the team stalled for seconds: SZ_TEAM_SPIN_CAP): the wave that gives up raises
@@ -2595,7 +2625,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks)
         return;
-    const HashTab<true> tab{dyn_tab, nullptr, nullptr};
+    const HashTab<true> tab{dyn_tab, nullptr, nullptr, nullptr};
     // (1 KiB steps of match extension: the blocks are small and the kernel runs four waves per SIMD)
     const uint32_t op = compress_one_block<0, true, HashTab<true>, true, 1>(tab, src + (uint64_t)b * block_bytes, block_bytes,
                                                     dst + (uint64_t)b * dst_stride, flags, lane);
