@@ -2134,6 +2134,16 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
     return poisoned ? 0xfffffffeu : op;
 }
 
+// A pointer made from an integer (the team kernel reads its arguments as integers from the kernel-argument segment)
+// has no address space for the compiler: every access through it becomes a FLAT instruction, which counts in BOTH
+// memory counters -- each wait for an LDS result then also waits for every load in flight.  Said here: global memory.
+template <typename T>
+__device__ __forceinline__ T *as_global(uint64_t addr)
+{
+    typedef __attribute__((address_space(1))) T GT;
+    return (T *)(GT *)(uintptr_t)addr;
+}
+
 // block length: explicit per block, or the fragments of one contiguous input (ragged tail), or fixed
 __device__ __forceinline__ uint32_t block_length(const uint32_t *__restrict__ in_len, uint64_t total_len,
                                                  uint64_t in_stride, uint32_t b)
@@ -2523,11 +2533,11 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
                 store_len(b, 0xffffffffu);
                 continue;
             }
-            uint16_t *my_glob = reinterpret_cast<uint16_t *>(uni64((uint64_t)(uintptr_t)a->scratch_tables)) +
+            uint16_t *my_glob = as_global<uint16_t>(uni64((uint64_t)(uintptr_t)a->scratch_tables)) +
                                 (size_t)(blockIdx.x * (kLoneWaves > 0 ? kLoneWaves : 1) + lw) * kMaxTable;
             const HashTab<false> gtab{nullptr, my_glob, lone_bm + lw * kGlobLdsWords + kGlobOccWords, lone_bm + lw * kGlobLdsWords};
-            const uint8_t *in_b = reinterpret_cast<const uint8_t *>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
-            uint8_t *out_b = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
+            const uint8_t *in_b = as_global<const uint8_t>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
+            uint8_t *out_b = as_global<uint8_t>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
             const uint32_t op = compress_one_block<0, true>(gtab, in_b, n, out_b, uni(a->flags), lane);
 #ifdef SZ_EXP_COUNT
             store_len(b, op | 0x80000000u);  // (tools/rolecount.hip: a block done by a lone wave)
@@ -2585,8 +2595,8 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
 #ifdef SZ_TRACE
         team.trace = b < kTraceBlocks && g_trace ? g_trace + ((size_t)b * kTeamWaves + wave) * kTraceCap : nullptr;
 #endif
-        const uint8_t *in_b = reinterpret_cast<const uint8_t *>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
-        uint8_t *out_b = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
+        const uint8_t *in_b = as_global<const uint8_t>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
+        uint8_t *out_b = as_global<uint8_t>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
         const uint32_t op = compress_one_block<0, true, HashTab<true>, true, SZ_MATCH_PIECES, WaveTeam<kTeamWaves>>(
             tab, in_b, n, out_b, uni(a->flags), lane, team);
         if (op != kTeamNotMine) {
