@@ -25,8 +25,6 @@
 
 namespace szk {
 
-// Diagnostic build only (tools/chainprof.hip compiles this file with -DSZ_PROF): cycle stamps per
-// phase, summed per block into g_prof.  Expands to nothing in the product build.
 // Placed behind a per-lane `if` that would otherwise be the last statement of a wave-uniform branch
 // arm: keeps the point where the lanes meet again a block of its own.  Without it that point is merged
 // with the point where the wave-uniform arms meet, and the compiler then has to assume that every value
@@ -41,57 +39,7 @@ namespace szk {
 #define SZ_MATCH_PIECES 4
 #endif
 
-// Analysis builds only (-DSZ_MARK): comments in the ISA at the phases of the fast dense path.
-#ifdef SZ_MARK
-#define MARK(name) asm volatile("; MARK " name)
-#else
-#define MARK(name) do { } while (0)
-#endif
-
-// Diagnostic build only (tools/teamtrace.hip, -DSZ_TRACE): time line of the team kernel's turns.  The waves of
-// the first blocks store (s_memtime << 28 | turn << 4 | phase) at the phase boundaries of every turn.
-#ifdef SZ_TRACE
-__device__ unsigned long long *g_trace;  // [traced blocks][waves][kTraceCap]
-static constexpr uint32_t kTraceCap = 16384, kTraceBlocks = 8;
-#define TRACE(id) do { if (team.trace && trn_ < kTraceCap) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); team.trace[trn_++] = (t_ << 28) | ((unsigned long long)(myturn & 0xffffffu) << 4) | (id); } } while (0)
-#else
-#define TRACE(id) do { } while (0)
-#endif
-
-#ifdef SZ_EXP_COUNT
-__device__ unsigned long long g_finish[1u << 18];  // (tools/rolecount.hip: s_memtime at which each block was finished)
-#endif
-#ifdef SZ_PROF
-__device__ unsigned long long g_prof[160];  // [128,160): phases of match_length (16 sums, 16 counts), all waves
-#define ML_START() unsigned long long mlt_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mlt_) :: "memory")
-#define ML_LAP(i) do { unsigned long long t2_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); if (lane == 0) { atomicAdd(&g_prof[128 + (i)], t2_ - mlt_); atomicAdd(&g_prof[144 + (i)], 1ull); } mlt_ = t2_; } while (0)  // [0,64): waves with the table in LDS (32 sums, 32 counts), [64,128): in global memory
-#define PROF_DECL unsigned long long pt_ = 0, pacc_[32] = {}; unsigned pcnt_[32] = {};
-#define PROF_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt_) :: "memory"); } while (0)
-#define PROF_LAP(i) do { unsigned long long t2_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
-#define PROF_LAPV(i) do { unsigned long long t2_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); pacc_[i] += t2_ - pt_; pcnt_[i]++; pt_ = t2_; } while (0)
-#define PROF_ADD(i, v) do { pacc_[i] += (unsigned long long)(v); pcnt_[i]++; } while (0)
-#define PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) { const int b_ = Tab::kInLds ? 0 : 64; for (int i_ = 0; i_ < 32; i_++) { atomicAdd(&g_prof[b_ + i_], pacc_[i_]); atomicAdd(&g_prof[b_ + 32 + i_], (unsigned long long)pcnt_[i_]); } } } while (0)
-#else
-#define PROF_DECL
-#define PROF_START() do { } while (0)
-#define PROF_LAP(i) do { } while (0)
-#define PROF_LAPV(i) do { } while (0)
-#define PROF_ADD(i, v) do { } while (0)
-#define PROF_FLUSH() do { } while (0)
-#define ML_START() do { } while (0)
-#define ML_LAP(i) do { } while (0)
-#endif
-#if defined(SZ_PE) || defined(SZ_PROF)
-__device__ unsigned long long g_pe[65536 * 4];
-#endif
-#if defined(SZ_PE) || defined(SZ_PROF)
-// block phases (tools/c3prof.hip): 28 entry -> stream requested, 29 -> main loop, 30 main loop, 31 -> return; s_memtime (shader clock)
-#define PE_START() unsigned long long pe_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pe_) :: "memory")
-#define PE_LAP(i) do { unsigned long long t2_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); if (lane == 0) g_pe[(blockIdx.x & 0xffffu) * 4u + ((i) - 28)] = t2_ - pe_; pe_ = t2_; } while (0)  // (one slot per block and phase: plain stores, nothing shared)
-#else
-#define PE_START() do { } while (0)
-#define PE_LAP(i) do { } while (0)
-#endif
+#include "diag.h"  // MARK / TRACE / PROF_* / PE_*: nothing in the product build
 
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxTable = 16384u;
@@ -385,6 +333,9 @@ __device__ __forceinline__ uint32_t sel6(uint32_t r0, uint32_t r1, uint32_t r2, 
 // NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
 // loads/stores with a vmcnt(0) wait after each.  The places that need "really re-read memory"
 // (other lanes of the same store may have won the bucket) use a compiler barrier.
+#ifndef SZ_GLOB_BM_LOG2
+#define SZ_GLOB_BM_LOG2 13  // bits of the bucket number that index a global-table wave's scratch bitmap
+#endif
 template <bool in_lds>
 struct HashTab {
     uint16_t *lds;
@@ -440,9 +391,9 @@ struct HashTab {
     }
     // global home: the scratch bitmap's word and bit of bucket h (13 of its 14 bits: two buckets share a bit, and a
     // lane that finds its bit set by the other bucket is told apart by the full hashes where the cut is worked out)
-    __device__ __forceinline__ uint32_t *bm_word(uint32_t h) const { return bm + ((h & 8191u) >> 5); }
+    __device__ __forceinline__ uint32_t *bm_word(uint32_t h) const { return bm + ((h & ((1u << SZ_GLOB_BM_LOG2) - 1u)) >> 5); }
 };
-static constexpr uint32_t kGlobBmWords = 256;   // scratch bitmap of a global-table wave: 8192 bits
+static constexpr uint32_t kGlobBmWords = (1u << SZ_GLOB_BM_LOG2) / 32u;  // scratch bitmap of a global-table wave: 8192 bits
 static constexpr uint32_t kGlobOccWords = 512;  // occupancy bitmap: 16384 bits
 static constexpr uint32_t kGlobLdsWords = kGlobBmWords + kGlobOccWords;  // per global-table wave: 3 KiB of LDS
 
@@ -591,9 +542,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
     // the others wait for a token.  Blocks too short for the fast dense path are wave 0's alone.
     bool holder = true, own_op = true, team_gone = false, team_lost = false;
     uint32_t myturn = 0;
-#ifdef SZ_TRACE
-    uint32_t trn_ = 0;
-#endif
+    TRACE_DECL;
     if constexpr (kTeamW > 1) {
         holder = own_op = team.wave == 0;
         myturn = team.wave;
@@ -836,10 +785,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 poisoned = true;
                 break;
             }
-#ifdef SZ_ABLATION
-            if (flags & 0x200u)  // timing ablation: no match finding at all (one literal)
-                break;
-#endif
+            ABLATION_BREAK_IF(flags & 0x200u);  // (-DSZ_ABLATION timing builds: no match finding at all, one literal)
 
             if constexpr (kTeamW > 1) {
                 // (blocks under 1 KiB are wave 0's alone -- the others have left --: general code only)
@@ -1970,9 +1916,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     }
                     const uint32_t incl = wave_inclusive_sum(cnt);
                     uint8_t *o = out + op + (incl - cnt);
-#ifdef SZ_ABLATION
-                    if (!(flags & 0x400u))  // timing ablation: no element stores
-#endif
+                    if (ABLATION_KEEPS(!(flags & 0x400u)))  // (-DSZ_ABLATION timing builds: no element stores)
                     {
                     if (cnt >= 1) o[0] = (uint8_t)word;
                     if (cnt >= 2) o[1] = (uint8_t)(word >> 8);
@@ -2539,16 +2483,8 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             const uint8_t *in_b = as_global<const uint8_t>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
             uint8_t *out_b = as_global<uint8_t>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
             const uint32_t op = compress_one_block<0, true>(gtab, in_b, n, out_b, uni(a->flags), lane);
-#ifdef SZ_EXP_COUNT
-            store_len(b, op | 0x80000000u);  // (tools/rolecount.hip: a block done by a lone wave)
-            {
-                unsigned long long t_;
-                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");  // (100 MHz, one clock for the whole GPU)
-                g_finish[b & 0x3ffffu] = t_;  // (every lane, same address, same value)
-            }
-#else
-            store_len(b, op);
-#endif
+            store_len(b, EXP_LONE_MARK(op));
+            EXP_FINISHED(b);
         }
         return;
     }
@@ -2592,9 +2528,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
                 store_len(b, 0xffffffffu);
             continue;
         }
-#ifdef SZ_TRACE
-        team.trace = b < kTraceBlocks && g_trace ? g_trace + ((size_t)b * kTeamWaves + wave) * kTraceCap : nullptr;
-#endif
+        TRACE_ATTACH(team, b, wave, kTeamWaves);
         const uint8_t *in_b = as_global<const uint8_t>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
         uint8_t *out_b = as_global<uint8_t>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
         const uint32_t op = compress_one_block<0, true, HashTab<true>, true, SZ_MATCH_PIECES, WaveTeam<kTeamWaves>>(
@@ -2611,13 +2545,8 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             if (op == kTeamLost)
                 break;
         }
-#ifdef SZ_EXP_COUNT
-        if (op != kTeamNotMine && op != kTeamLost) {
-            unsigned long long t_;
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
-            g_finish[b & 0x3ffffu] = t_;
-        }
-#endif
+        if (op != kTeamNotMine && op != kTeamLost)
+            EXP_FINISHED(b);
     }
 }
 

@@ -31,9 +31,9 @@ object SnappyHip {
   /** Contiguous block range [begin, end) of rank `rank` of `world` (one process per GPU; no data-path collective). */
   @native def shardRange(nBlocks: Long, rank: Int, world: Int): Array[Long]
 
-  /** The test sentence of tests/compression.c, round trip. */
+  /** The test sentence of tests/compression.c:43, round trip (expected: 130 -> 112 bytes, the oracle's and libsnappy 1.1.8's size). */
   def main(args: Array[String]): Unit = {
-    val text = "The quick brown fox jumps over the lazy dog. The quick brown fox jumps over the lazy dog again and again and again."
+    val text = "If Tid the thistle sifter lifts his sieve of sifted thistles, then he'll shift the thistles in his sifting sieve to live unsifted."  // tests/compression.c:43 (130 bytes -> 112)
     val raw = text.getBytes("US-ASCII")
     val src = ByteBuffer.allocateDirect(raw.length); src.put(raw); src.flip()
     val dst = ByteBuffer.allocateDirect(maxCompressedLength(raw.length).toInt)

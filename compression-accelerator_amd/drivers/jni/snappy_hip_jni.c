@@ -25,8 +25,9 @@ JNIEXPORT jlong JNICALL Java_snappyhip_SnappyHip_00024_compress(JNIEnv *e, jobje
 {
     (void)o;
     void *s = (*e)->GetDirectBufferAddress(e, src), *d = (*e)->GetDirectBufferAddress(e, dst);
-    if (!s || !d || len < 0 || (*e)->GetDirectBufferCapacity(e, dst) < (jlong)sz_max_compressed_length((size_t)len))
-        return (jlong)SZ_EINVAL;  /* (the RoCC command passes no bound for dst: checked here, where it is known) */
+    if (!s || !d || len < 0 || (*e)->GetDirectBufferCapacity(e, src) < (jlong)len ||
+        (*e)->GetDirectBufferCapacity(e, dst) < (jlong)sz_max_compressed_length((size_t)len))
+        return (jlong)SZ_EINVAL;  /* (the RoCC command passes no bound for src or dst: checked here, where they are known) */
     return rocc(SZ_ROCC_COMPRESS, s, len, d);
 }
 
@@ -35,7 +36,7 @@ JNIEXPORT jlong JNICALL Java_snappyhip_SnappyHip_00024_uncompress(JNIEnv *e, job
     (void)o;
     void *s = (*e)->GetDirectBufferAddress(e, src), *d = (*e)->GetDirectBufferAddress(e, dst);
     size_t ulen = 0;
-    if (!s || !d || len <= 0)
+    if (!s || !d || len <= 0 || (*e)->GetDirectBufferCapacity(e, src) < (jlong)len)
         return (jlong)SZ_EINVAL;
     int rc = sz_get_uncompressed_length(s, (size_t)len, &ulen);
     if (rc != SZ_OK)
@@ -50,6 +51,8 @@ JNIEXPORT jint JNICALL Java_snappyhip_SnappyHip_00024_compressBlocksDevice(JNIEn
                                                                           jlong stream)
 {
     (void)e; (void)o;
+    if (n_blocks < 0 || slot_stride <= 0)  /* (a negative jint would become a huge uint32 block count) */
+        return (jint)SZ_EINVAL;
     return (jint)sz_compress_blocks_hip((const void *)(uintptr_t)d_src, SZ_BLOCK_SIZE, NULL, (uint32_t)n_blocks,
                                         (void *)(uintptr_t)d_dst, (size_t)slot_stride, (uint32_t *)(uintptr_t)d_out_len,
                                         SZ_FLAG_BLOCK_VARINT, (void *)(uintptr_t)stream);

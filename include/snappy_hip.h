@@ -58,6 +58,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the 23 functions declared here are everything it exports. */
+#if defined(__GNUC__) || defined(__clang__)
+#define SZ_API __attribute__((visibility("default")))
+#else
+#define SZ_API
+#endif
+
 #define SZ_BLOCK_SIZE 65536u      /* Snappy fragment size: one block per wavefront */
 #define SZ_SLOT_STRIDE 76544u     /* default output slot: >= sz_max_compressed_length(65536)=76490, 128-B multiple */
 
@@ -98,14 +105,14 @@ extern "C" {
 /* ---- sizing ---------------------------------------------------------------------------- */
 
 /* 32 + n + n/6, identical to snappy::MaxCompressedLength. */
-size_t sz_max_compressed_length(size_t n);
+SZ_API size_t sz_max_compressed_length(size_t n);
 
 /* ---- device-resident batch API (the hot path) --------------------------------------------
  * Block b reads d_src + b*in_stride, d_in_len[b] bytes (d_in_len == NULL: in_stride bytes each;
  * every length must be <= 65536), and writes d_dst + b*dst_stride and d_out_len[b].
  * dst_stride must be >= sz_max_compressed_length(longest block) + 5.
  * One 64-lane wavefront per block, hash table in LDS. */
-int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *d_in_len,
+SZ_API int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *d_in_len,
                            uint32_t n_blocks, void *d_dst, size_t dst_stride,
                            uint32_t *d_out_len, uint32_t flags, void *stream);
 
@@ -115,12 +122,12 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
  * one-wavefront-per-block kernel, multi_start / multi_stop around the persistent kernel for compressible launches
  * (both are enqueued when a data sample chooses between them; the one not chosen exits at once).  NULL handles are
  * skipped; one shot.  Events are created and read by the caller (hipEventCreate, hipEventElapsedTime). */
-int sz_profile_next_launch(void *single_start, void *single_stop, void *multi_start, void *multi_stop);
+SZ_API int sz_profile_next_launch(void *single_start, void *single_stop, void *multi_start, void *multi_stop);
 
 /* Same kernel for ONE contiguous input of n bytes (n < 2^32) cut into consecutive 64 KiB fragments
  * (the last one ragged): fragment k goes to d_slots + k*slot_stride, its length to d_len[k].
  * Number of fragments = ceil(n / 65536).  This is the fragment loop of snappy::Compress. */
-int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t slot_stride,
+SZ_API int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t slot_stride,
                            uint32_t *d_len, uint32_t flags, void *stream);
 
 /* Exclusive prefix sum of d_len[0..n_blocks) + base into d_off[0..n_blocks], d_off[n_blocks] =
@@ -129,14 +136,14 @@ int sz_compress_stream_hip(const void *d_src, size_t n, void *d_slots, size_t sl
  * d_off must hold n_blocks+1 uint64.  A d_len[b] above slot_stride (the compress kernels mark a
  * block they could not take with 0xffffffff) packs nothing for that slot and makes
  * d_off[n_blocks] = UINT64_MAX. */
-int sz_pack_stream_hip(const void *d_slots, size_t slot_stride, const uint32_t *d_len,
+SZ_API int sz_pack_stream_hip(const void *d_slots, size_t slot_stride, const uint32_t *d_len,
                        uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
                        void *stream);
 
 /* Batch decompression: stream b is d_src + b*src_stride, d_src_len[b] bytes (a raw Snappy
  * stream with preamble); decoded bytes go to d_dst + b*dst_stride (capacity dst_stride),
  * d_out_len[b] receives the decoded size, d_status[b] 0 or SZ_ECORRUPT/SZ_ENOSPC. */
-int sz_uncompress_blocks_hip(const void *d_src, size_t src_stride, const uint32_t *d_src_len,
+SZ_API int sz_uncompress_blocks_hip(const void *d_src, size_t src_stride, const uint32_t *d_src_len,
                              uint32_t n_streams, void *d_dst, size_t dst_stride,
                              uint32_t *d_out_len, int32_t *d_status, void *stream);
 
@@ -148,7 +155,7 @@ int sz_uncompress_blocks_hip(const void *d_src, size_t src_stride, const uint32_
  * way to decompress one large snappy::Compress stream fast; without the offsets a stream has to
  * be parsed serially (sz_uncompress_blocks_hip with one stream, sz_uncompress).
  * d_out_len[b] / d_status[b] as for sz_uncompress_blocks_hip. */
-int sz_uncompress_packed_hip(const void *d_packed, const uint64_t *d_off, uint32_t n_blocks,
+SZ_API int sz_uncompress_packed_hip(const void *d_packed, const uint64_t *d_off, uint32_t n_blocks,
                              uint64_t total_ulen, void *d_dst, uint32_t *d_out_len, int32_t *d_status,
                              void *stream);
 
@@ -163,36 +170,36 @@ int sz_uncompress_packed_hip(const void *d_packed, const uint64_t *d_off, uint32
  * Otherwise the stream is malformed OR simply was not written in 64 KiB fragments (every stock
  * Snappy compressor does write them): decode it with sz_uncompress_blocks_hip as one stream, which
  * also tells the two apart. */
-size_t sz_uncompress_stream_work_bytes(size_t n, uint64_t ulen);
-int sz_uncompress_stream_hip(const void *d_src, size_t n, size_t body, uint64_t ulen, void *d_dst,
+SZ_API size_t sz_uncompress_stream_work_bytes(size_t n, uint64_t ulen);
+SZ_API int sz_uncompress_stream_hip(const void *d_src, size_t n, size_t body, uint64_t ulen, void *d_dst,
                              void *d_work, size_t work_bytes, int32_t *d_status3, void *stream);
 
 /* ---- host-buffer convenience API (what the snappy:: facade and the RoCC surface call) ---- */
 
 /* Exactly the bytes of snappy::Compress(src, n): varint32(n) + bodies of consecutive 64 KiB
  * fragments, all fragments compressed on the GPU in one launch.  n < 2^32. */
-int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len);
+SZ_API int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len);
 
 /* snappy::Uncompress on the GPU.  *out_len receives the decoded size.  A stream of four or more
  * 64 KiB fragments is indexed in parallel on the GPU (where does each fragment begin) and decoded
  * one wavefront per fragment; shorter streams, and streams that were not written fragment by
  * fragment, are decoded by a single wavefront. */
-int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len);
+SZ_API int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len);
 
 /* snappy::GetUncompressedLength (host-side varint parse, no GPU needed). */
-int sz_get_uncompressed_length(const void *src, size_t n, size_t *result);
+SZ_API int sz_get_uncompressed_length(const void *src, size_t n, size_t *result);
 
 /* ---- RoCC command surface ----------------------------------------------------------------
  * Per-thread accelerator state (the latched length), one outstanding command, blocking, as
  * CompressionAccelerator.scala:72 (cmd.ready := !busy).  COMPRESS writes the full Snappy raw
  * stream (preamble + elements) so that UNCOMPRESS and any software Snappy can read it back.
  * Returns 0 and sets *rd, or a negative SZ_E* (bad channel/funct, no GPU). */
-int sz_rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2, uint64_t *rd);
+SZ_API int sz_rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2, uint64_t *rd);
 
 /* Same, shaped for the instruction macros (include/rocc_host_shim.h): returns rd; on error
  * returns (uint64_t)-1 and records the code for sz_rocc_last_error(). */
-uint64_t rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2);
-int sz_rocc_last_error(void);
+SZ_API uint64_t rocc_cmd(int channel, int funct, uint64_t rs1, uint64_t rs2);
+SZ_API int sz_rocc_last_error(void);
 
 /* ---- multi-GPU (the Python side of the same two steps: sharding.py) -------
  * The path shards by contiguous ranges of independent 64 KiB blocks, one process per GPU, no data-path
@@ -202,30 +209,30 @@ int sz_rocc_last_error(void);
  * helpers are host arithmetic and need no GPU. */
 /* The balanced contiguous range of rank `rank` of `world` (the first n_blocks_total % world ranks get one
  * block more).  SZ_EINVAL if world == 0, rank >= world or a pointer is null. */
-int sz_shard_range(uint64_t n_blocks_total, uint32_t rank, uint32_t world, uint64_t *begin, uint64_t *end);
+SZ_API int sz_shard_range(uint64_t n_blocks_total, uint32_t rank, uint32_t world, uint64_t *begin, uint64_t *end);
 /* Layout of the whole packed stream from the gathered lengths: offsets[i] = base + lens[0] + ... + lens[i-1]
  * for i = 0 .. n_blocks (base = bytes of the stream's preamble).  SZ_ECORRUPT, and *bad_block set if not
  * null, if a length is one of the kernels' markers (>= 0xfffffffd: the block was not compressed) or
  * exceeds `slot_stride`. */
-int sz_stream_offsets(const uint32_t *lens, uint64_t n_blocks, uint64_t base, uint64_t slot_stride,
+SZ_API int sz_stream_offsets(const uint32_t *lens, uint64_t n_blocks, uint64_t base, uint64_t slot_stride,
                       uint64_t *offsets, uint64_t *bad_block);
 
 /* ---- misc ------------------------------------------------------------------------------- */
 /* Frees the calling thread's cached device workspace (its stream, five buffers and the 64 MiB below),
  * used by the host-buffer API and the RoCC surface.  It is NOT freed when the thread exits (the HIP
  * runtime may be gone by then): a thread pool that retires threads calls this in each of them first. */
-void sz_release_thread_resources(void);
+SZ_API void sz_release_thread_resources(void);
 /* Frees the 64 MiB workspace the compress entry points keep for `stream` on the current device
  * (waits for the stream first).  The workspace is created by the first launch on the stream that
  * has enough blocks for the multi-wave kernel (8 x CUs), never by small calls.  Call this before
  * destroying a stream that was used for compression if the process creates many; the next large
  * compress call on the stream allocates a new one.  Host threads may launch on one stream at the
  * same time: the launch sequence of each call is enqueued as a unit. */
-int sz_release_stream_resources(void *stream);
-int sz_device_count(void);            /* number of visible GPUs (0 if none / no driver) */
-int sz_last_hip_error(void);          /* last hipError_t seen by this thread */
-const char *sz_strerror(int code);
-const char *sz_version(void);
+SZ_API int sz_release_stream_resources(void *stream);
+SZ_API int sz_device_count(void);            /* number of visible GPUs (0 if none / no driver) */
+SZ_API int sz_last_hip_error(void);          /* last hipError_t seen by this thread */
+SZ_API const char *sz_strerror(int code);
+SZ_API const char *sz_version(void);
 
 #ifdef __cplusplus
 }

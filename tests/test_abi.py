@@ -50,9 +50,13 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), "libsnappy_hip.so does not export %s" % s
     assert set(declared) == set(P.ABI_SYMBOLS)
+    # ... and NOTHING else: no kernel launch stub, no C++ template instance, no __hip_cuid_* marker has default
+    # visibility (-fvisibility=hidden + SZ_API on the declarations + csrc/exports.map)
     out = subprocess.check_output(["nm", "-D", "--defined-only", P.LIB_PATH]).decode()
-    exported = set(re.findall(r" T ((?:sz_|rocc_)\w+)", out))
+    exported = set(line.split()[-1] for line in out.splitlines() if line.strip())
     assert exported == set(declared), exported ^ set(declared)
+    hdr = open(os.path.join(ROOT, "include", "snappy_hip.h")).read()
+    assert hdr.count("SZ_API ") == len(declared) + 1, "every declaration carries SZ_API (+ its definition)"
 
 
 def test_no_torch_or_oracle_in_the_abi_library():

@@ -13,6 +13,8 @@ libs = sys.argv[1].split(",")
 works = [(w.split(":")[0], int(w.split(":")[1])) for w in sys.argv[2].split(",")]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 dev = torch.device("cuda:0")
+modes = [(p.split("@")[1] if "@" in p else None) for p in libs]  # lib.so@dual: SZ_KERNEL=dual for that build's launches
+libs = [p.split("@")[0] for p in libs]
 L = []
 for p in libs:
     l = ctypes.CDLL(os.path.join(ROOT, p) if not os.path.isabs(p) else p)
@@ -26,6 +28,11 @@ for kind, nb in works:
     dst = torch.zeros(nb * SLOT, dtype=torch.uint8, device=dev)
     ol = torch.zeros(nb, dtype=torch.int32, device=dev)
     def run(l):
+        m = modes[L.index(l)]
+        if m:
+            os.environ["SZ_KERNEL"] = m
+        else:
+            os.environ.pop("SZ_KERNEL", None)
         rc = l.sz_compress_blocks_hip(src.data_ptr(), 65536, None, nb, dst.data_ptr(), SLOT, ol.data_ptr(), 1, stream)
         assert rc == 0, rc
     for l in L:
@@ -38,8 +45,9 @@ for kind, nb in works:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); run(l); b.record(); torch.cuda.synchronize()
             ts[i].append(a.elapsed_time(b))
-    for p, t in zip(libs, ts):
+    for p, m, t in zip(libs, modes, ts):
         t.sort()
+        p = p + ("@" + m if m else "")
         print("%-30s %-5s nb=%-6d min %.3f  med %.3f  mean %.3f ms -> %.1f GB/s (median)" % (
             os.path.basename(p), kind, nb, t[0], t[len(t) // 2], statistics.mean(t), nb * 65536 / t[len(t) // 2] / 1e6), flush=True)
     del src, dst, ol
