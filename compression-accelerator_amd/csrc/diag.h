@@ -39,9 +39,11 @@ static constexpr uint32_t kTraceCap = 16384, kTraceBlocks = 8;
 #ifdef SZ_EXP_COUNT
 __device__ unsigned long long g_finish[1u << 18];  // (tools/rolecount.hip: s_memrealtime at which each block was finished; 100 MHz, one clock for the whole GPU)
 #define EXP_LONE_MARK(op) ((op) | 0x80000000u)  // a block done by a lone wave
+#define EXP_SINGLE_MARK(op) ((op) | 0x40000000u)  // a block done by the single kernel (tests/test_gpu_routing.py: who wrote which block)
 #define EXP_FINISHED(b) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_finish[(b) & 0x3ffffu] = t_; } while (0)  // (every lane, same address, same value)
 #else
 #define EXP_LONE_MARK(op) (op)
+#define EXP_SINGLE_MARK(op) (op)
 #define EXP_FINISHED(b) do { } while (0)
 #endif
 #ifdef SZ_PROF

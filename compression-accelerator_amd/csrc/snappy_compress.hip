@@ -2179,7 +2179,11 @@ __global__ __launch_bounds__(256) void sample_compressibility_kernel(
     if (t == 0)
         wg_dups = 0;
     __syncthreads();
-    const uint32_t b = (uint32_t)(((uint64_t)blockIdx.x * n_blocks) / gridDim.x);
+    // one block out of each of gridDim.x equal stretches of the launch, at a place inside its stretch that follows no
+    // period (evenly spaced samples met only the text blocks of a launch whose every 16th block was text)
+    const uint32_t b0 = (uint32_t)(((uint64_t)blockIdx.x * n_blocks) / gridDim.x);
+    const uint32_t b1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_blocks) / gridDim.x);
+    const uint32_t b = b0 + (b1 > b0 ? ((blockIdx.x * 0x9e3779b1u) >> 12) % (b1 - b0) : 0u);
     uint32_t n = block_length(in_len, total_len, in_stride, b);
     const uint8_t *in = src + (uint64_t)b * in_stride;
     if (t < 64) {  // the cost classes the launch holds (does ordering its queue pay?)
@@ -2204,97 +2208,69 @@ __global__ __launch_bounds__(256) void sample_compressibility_kernel(
 }
 
 
-// ---- longest blocks first (round 3): the persistent kernels hand out blocks from one queue, and a launch that
-// mixes kinds of data ends with a tail in which the last expensive blocks run alone (a 64 KiB block of text takes
-// ~100 x as long as an incompressible one, ~10 x as long as one that is a few long matches).  Blocks cannot be
-// split, so the lever is their order: a cheap estimate per block, three cost classes, the expensive class first.
-//   * repeats among the 4-byte shingles of the block's first 1 KiB (the launch sample's measure, per block):
-//     few -> the scan accelerates, strided probes, cheap (class 0);
-//   * otherwise, distinct 8-byte strings among 128 samples spread evenly over the block: few -> the block
-//     repeats itself at long range (long matches skip most of it), medium (class 1); many -> dense parse
-//     of the whole block, expensive (class 2).
-// The estimate only orders the queue: every block is compressed by the same code whatever its class.
-// select[4..6] = blocks per class, select[8..10] = cursors of the placement, select[3] = n_blocks for the
-// kernel that reads the queue.  `cls` = one byte per block (the upper half of the queue buffer).
-__global__ __launch_bounds__(256) void classify_blocks_kernel(
-    const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len, uint64_t total_len,
-    uint32_t n_blocks, uint8_t *__restrict__ cls, uint32_t *__restrict__ select, uint32_t auto_mode)
+// ---- blocks, not launches, are routed (round 5), and the expensive ones go first (round 3)
+// A launch whose sample has met more than one cost class (launch_is_mixed) is compressed by BOTH kernels: the single
+// kernel is started for every block, works out the block's class itself (block_cost_class: ~1 us of one wave) and
+// keeps the blocks of class 0 -- no repeats among the shingles of their first KiB: the scan accelerates, the block
+// streams through the register file, 26 us -- while a block of class 1 or 2 is put into the persistent kernel's queue
+// (one atomic) and left; the team kernel, next on the stream, takes the queue: class 2 first (dense parse of the
+// whole block: a 64 KiB block of text takes ~100 x as long as an incompressible one), then class 1 (few distinct
+// strings among 128 samples spread over the block: long matches skip most of it).  Blocks cannot be split, so a
+// mixed launch ends with its last expensive blocks running alone, and the lever is their order.  No host
+// synchronisation, graph-capturable; a wrong class only costs speed, every kernel writes the same bytes.
+// A launch of one class runs as before: one kernel for all its blocks by the sample's verdict, no queue.
+//   select[4 + c] = blocks of class c in the queue (c = 1, 2); queue[0 .. half) class 2, queue[half ..) class 1.
+// (Rounds 3-4 ordered the queue with two kernels of their own and left the incompressible third of a mixed launch
+// to the persistent kernel's general code at 145 us a block; a compressible minority in an incompressible launch
+// went through the single kernel's instance without the fast dense path at half the team kernel's rate.)
+__device__ __forceinline__ bool launch_is_routed(const uint32_t *__restrict__ select, uint32_t queue_half)
 {
-    __shared__ uint32_t bitmaps[4][384];
-    if (auto_mode && !(prefers_dual(select) && launch_is_mixed(select)))
-        return;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // one wave per block; a bounded grid that strides over the launch (a launch that does not order its queue pays
-    // for the workgroups that leave at once: a few microseconds, which a 0.8 ms incompressible launch notices)
-    for (uint32_t b = blockIdx.x * 4u + wave; b < n_blocks; b += gridDim.x * 4u) {
-        for (uint32_t i = lane; i < 384; i += 64)
-            bitmaps[wave][i] = 0;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t n = block_length(in_len, total_len, in_stride, b);
-        const uint32_t c = block_cost_class(src + (uint64_t)b * in_stride, n > kMaxBlock ? 0 : n, lane, bitmaps[wave]);
-        if (lane == 0) {
-            cls[b] = (uint8_t)c;
-            atomicAdd(&select[4 + c], 1u);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-__global__ __launch_bounds__(256) void place_blocks_kernel(const uint8_t *__restrict__ cls, uint32_t n_blocks,
-                                                          uint32_t *__restrict__ queue, uint32_t *__restrict__ select,
-                                                          uint32_t auto_mode)
-{
-    if (auto_mode && !(prefers_dual(select) && launch_is_mixed(select)))
-        return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n2 = select[6], n1 = select[5];
-    for (uint32_t i0 = blockIdx.x * 256u; i0 < n_blocks; i0 += gridDim.x * 256u) {
-        const uint32_t i = i0 + threadIdx.x;
-        const uint32_t c = i < n_blocks ? cls[i] : 3u;
-#pragma unroll
-        for (uint32_t k = 0; k < 3; k++) {  // one atomic per wave and class
-            const uint64_t m = ballot64(c == k);
-            if (m == 0)
-                continue;
-            uint32_t base = 0;
-            if (lane == 0)
-                base = atomicAdd(&select[8 + k], (uint32_t)__builtin_popcountll(m));
-            base = uni(base) + (k == 2 ? 0u : k == 1 ? n2 : n2 + n1);  // expensive first, cheap last
-            if (c == k)
-                queue[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1))] = i;
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        select[3] = n_blocks;
+    return queue_half != 0 && launch_is_mixed(select);
 }
 
 // Single kernel: one 64-lane workgroup per block, table in LDS, whole block in registers.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void compress_blocks_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
-    uint32_t *__restrict__ out_len, uint32_t flags, const uint32_t *__restrict__ select)
+    uint32_t *__restrict__ out_len, uint32_t flags, uint32_t *__restrict__ select, uint32_t *__restrict__ queue,
+    uint32_t queue_half)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];  // the whole LDS budget: 32 KiB
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks)
         return;
-    if (select && prefers_dual(select))  // auto mode: the sampled data is compressible, the dual kernel runs
+    const bool routed = select && launch_is_routed(select, queue_half);
+    if (select && !routed && prefers_dual(select))  // auto mode, one kind of block: the sampled data is compressible, the team kernel runs
         return;
     const uint32_t n = block_length(in_len, total_len, in_stride, b);
     if (n > kMaxBlock) {  // caller error: flagged, nothing written
         out_len[b] = 0xffffffffu;  // (every lane, same address, same value: see the note at the dual kernel)
         return;
     }
+    if (routed) {
+        // a mixed launch: this block's own class decides who compresses it (the table's LDS is the classifier's scratch)
+        uint32_t *scratch = reinterpret_cast<uint32_t *>(lds_tab);
+        for (uint32_t i = lane; i < 384; i += 64)
+            scratch[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t c = uni(block_cost_class(src + (uint64_t)b * in_stride, n, lane, scratch));
+        if (c != 0) {
+            if (lane == 0)
+                queue[(c == 2 ? 0u : queue_half) + atomicAdd(&select[4 + c], 1u)] = b;
+            return;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     const HashTab<true> tab{lds_tab, nullptr, nullptr, nullptr};
     uint32_t op;
-    if (select)  // auto mode, and the sample says incompressible: the instance without the fast dense path
+    if (select)  // auto mode, and the sample (or this block's class) says incompressible: the instance without the fast dense path
         op = compress_one_block<64, false, HashTab<true>, false>(tab, src + (uint64_t)b * in_stride, n,
                                                                          dst + (uint64_t)b * dst_stride, flags, lane);
     else
         op = compress_one_block<64, false>(tab, src + (uint64_t)b * in_stride, n, dst + (uint64_t)b * dst_stride,
                                            flags, lane);
-    out_len[b] = op;  // (a9) every lane, same address, same value
+    out_len[b] = EXP_SINGLE_MARK(op);  // (a9) every lane, same address, same value
 }
 
 // Multi-wave ("dual") kernel: workgroups of kGroupWaves independent wavefronts, each compressing its
@@ -2316,15 +2292,12 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint8_t *__restrict__ dst, uint64_t dst_stride,
     uint32_t *__restrict__ out_len, uint32_t flags, uint16_t *scratch_tables,
-    uint32_t *__restrict__ select, const uint32_t *__restrict__ queue, uint32_t auto_mode)
+    uint32_t *__restrict__ select)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
     __shared__ __attribute__((aligned(16))) uint32_t dup_bm[(kGroupWaves - 1) * kGlobLdsWords];  // per global-table wave: scratch bitmap + occupancy bitmap
-    if ((auto_mode & 1u) && !prefers_dual(select))  // auto mode: incompressible sample, the single kernel ran
-        return;
-    if ((auto_mode & 2u) && (auto_mode & 1u) && !launch_is_mixed(select))
-        queue = nullptr;  // an order queue, and the sample found one kind of block only: it was not filled
-    const uint32_t n_work = queue ? uni(select[3]) : n_blocks;
+    // (only ever launched by name -- SZ_KERNEL=dual --: every block of the launch, in index order)
+    const uint32_t n_work = n_blocks;
     if (blockIdx.x * kGroupWaves >= n_work)
         return;
     const uint32_t wave = uni(threadIdx.x >> 6);
@@ -2355,8 +2328,6 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
         b = uni(b);
         if (b >= n_work)
             break;
-        if (queue)
-            b = uni(queue[b]);
         const uint32_t n = block_length(in_len, total_len, in_stride, b);
         if (n > kMaxBlock) {
             out_len[b] = 0xffffffffu;
@@ -2411,8 +2382,9 @@ struct TeamArgs {
     uint32_t *out_len;
     uint16_t *scratch_tables;
     uint32_t *select;
-    const uint32_t *queue;
-    uint32_t n_blocks, flags, auto_mode;
+    const uint32_t *queue;  // routed launches: block indices, class 2 from [0], class 1 from [queue_half]
+    uint32_t n_blocks, flags, auto_mode;  // auto_mode bit 0: the launch was sampled (else: every block, by name)
+    uint32_t queue_half;    // 0: no routing
 };
 __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_eu(kHybridPerSimd, kHybridPerSimd))) void compress_blocks_team_kernel(TeamArgs args_in_kernarg)
 {
@@ -2428,15 +2400,13 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
         asm volatile("" : "+s"(p));
         return p;
     };
-    bool use_queue = ka()->queue != nullptr;
-    {
-        const uint32_t auto_mode = ka()->auto_mode;
-        if ((auto_mode & 1u) && !prefers_dual(ka()->select))  // auto mode: incompressible sample, the single kernel ran
-            return;
-        if ((auto_mode & 2u) && (auto_mode & 1u) && !launch_is_mixed(ka()->select))
-            use_queue = false;  // an order queue, and the sample found one kind of block only: it was not filled
-    }
-    const uint32_t n_work = use_queue ? uni(ka()->select[3]) : uni(ka()->n_blocks);
+    // routed (a mixed launch): the queue the single kernel has filled, expensive class first; else every block of the
+    // launch in index order -- if the sample says compressible
+    const bool use_queue = (ka()->auto_mode & 1u) != 0 && launch_is_routed(ka()->select, ka()->queue_half);
+    if ((ka()->auto_mode & 1u) != 0 && !use_queue && !prefers_dual(ka()->select))  // auto mode: incompressible sample, the single kernel ran
+        return;
+    const uint32_t n_q2 = use_queue ? uni(ka()->select[6]) : 0u;
+    const uint32_t n_work = use_queue ? n_q2 + uni(ka()->select[5]) : uni(ka()->n_blocks);
     if (blockIdx.x * (1u + kLoneWaves) >= n_work)
         return;
     const uint32_t wave = uni(threadIdx.x >> 6);
@@ -2451,7 +2421,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
         }
         return uni(b0);
     };
-    auto queued = [&](uint32_t i) -> uint32_t { return use_queue ? uni(ka()->queue[i]) : i; };
+    auto queued = [&](uint32_t i) -> uint32_t { return use_queue ? uni(ka()->queue[i < n_q2 ? i : ka()->queue_half + (i - n_q2)]) : i; };
     auto store_len = [&](uint32_t b, uint32_t v) { ka()->out_len[b] = v; };  // every lane, same address, same value
     if (threadIdx.x == 0) {
         __hip_atomic_store(&team_bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2603,6 +2573,8 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
     }
     const bool dual_ok = dual && dual->tables && n_blocks >= dual->min_blocks;
     const bool sampled = dual_ok && dual->mode == kDualAuto;
+    // blocks of a mixed launch are routed one by one (the single kernel queues what it leaves to the team kernel)
+    const uint32_t queue_half = sampled && dual->kernel == kKernelTeam && dual->queue && n_blocks <= dual->queue_cap / 2 ? dual->queue_cap / 2 : 0u;
     if (dual_ok)  // launch state := 0.  (A kernel, not hipMemsetAsync: captured into a hipGraph, the
                   // memset node made every replay after the first a no-op.)
         hipLaunchKernelGGL(reset_launch_state_kernel, dim3(1), dim3(64), 0, stream, dual->select);
@@ -2617,22 +2589,11 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
             (void)hipEventRecord(prof.single0, stream);
         hipLaunchKernelGGL(compress_blocks_kernel, dim3(n_blocks), dim3(64), 0, stream, src, in_stride, d_in_len,
                                total_len, n_blocks, dst, dst_stride, d_out_len, flags,
-                               sampled ? dual->select : (const uint32_t *)nullptr);
+                               sampled ? dual->select : (uint32_t *)nullptr, queue_half ? dual->queue : (uint32_t *)nullptr,
+                               queue_half);
         if (prof.single1)
             (void)hipEventRecord(prof.single1, stream);
     }
-    // longest blocks first: the queue of the persistent kernel in cost order
-    const bool ordered = dual_ok && dual->queue && n_blocks >= 256 && 2ull * n_blocks <= dual->queue_cap;
-    if (ordered) {
-        uint8_t *cls = reinterpret_cast<uint8_t *>(dual->queue + dual->queue_cap / 2);
-        const uint32_t cgrid = (n_blocks + 3) / 4 < 2048u ? (n_blocks + 3) / 4 : 2048u;
-        const uint32_t pgrid = (n_blocks + 255) / 256 < 256u ? (n_blocks + 255) / 256 : 256u;
-        hipLaunchKernelGGL(classify_blocks_kernel, dim3(cgrid), dim3(256), 0, stream, src, in_stride, d_in_len, total_len,
-                           n_blocks, cls, dual->select, sampled ? 1u : 0u);
-        hipLaunchKernelGGL(place_blocks_kernel, dim3(pgrid), dim3(256), 0, stream, cls, n_blocks,
-                           dual->queue, dual->select, sampled ? 1u : 0u);
-    }
-    const uint32_t *work_queue = ordered ? dual->queue : (const uint32_t *)nullptr;
     if (dual_ok) {
         // enough blocks to keep kGroupWaves waves per SIMD busy on every CU: persistent grid
         if (dual->kernel == kKernelTeam) {
@@ -2640,7 +2601,7 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
             tgrid = tgrid < dual->n_slots ? tgrid : dual->n_slots;
             static_assert(kLoneWaves <= (int)kDualTablesPerGroup, "the workspace has kDualTablesPerGroup tables per workgroup");
             const TeamArgs targs{src, in_stride, d_in_len, total_len, dst, dst_stride, d_out_len, dual->tables, dual->select,
-                                 work_queue, n_blocks, flags, (sampled ? 1u : 0u) | (ordered ? 2u : 0u)};
+                                 dual->queue, n_blocks, flags, sampled ? 1u : 0u, queue_half};
             if (prof.multi0)
                 (void)hipEventRecord(prof.multi0, stream);
             hipLaunchKernelGGL(compress_blocks_team_kernel, dim3(tgrid), dim3(64 * kHybridWaves), 0, stream, targs);
@@ -2654,7 +2615,7 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
             (void)hipEventRecord(prof.multi0, stream);
         hipLaunchKernelGGL(compress_blocks_dual_kernel, dim3(grid), dim3(64 * kGroupWaves), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dst, dst_stride, d_out_len, flags, dual->tables,
-                           dual->select, work_queue, (sampled ? 1u : 0u) | (ordered ? 2u : 0u));
+                           dual->select);
         if (prof.multi1)
             (void)hipEventRecord(prof.multi1, stream);
     }

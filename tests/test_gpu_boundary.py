@@ -262,9 +262,9 @@ def test_full_size_forced_kernels(mode, monkeypatch):
 
 def test_a_compressible_minority_inside_an_incompressible_launch(monkeypatch):
     """4 096 incompressible blocks with every 16th replaced by text or a low-entropy block (and two empty-ish
-    ones), default kernel choice: the launch sample finds it incompressible, so the single kernel -- the instance
-    built without the fast dense path -- compresses the text blocks too (a wrong guess per block only costs
-    speed); every block equals the oracle and decodes."""
+    ones), default kernel choice: the launch sample meets more than one kind of block, so every block is routed by
+    its own class -- the single kernel keeps the incompressible ones, the team kernel takes the rest
+    (tests/test_gpu_routing.py checks who wrote what); every block equals the oracle and decodes."""
     import sys
     import torch
     sys.path.insert(0, build_util.ROOT)
