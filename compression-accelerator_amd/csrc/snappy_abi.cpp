@@ -101,7 +101,7 @@ std::shared_ptr<DualSlot> dual_slot_for(hipStream_t stream, uint32_t n_blocks, s
         std::shared_ptr<DualSlot> slot(new DualSlot);
         slot->sc.n_slots = n_slots;
         void *t = nullptr, *g = nullptr, *q = nullptr;
-        const size_t gbytes = 64;  // launch state
+        const size_t gbytes = szk::kLaunchStateBytes;  // launch state (+ the sample's per-workgroup results)
         const size_t tbytes = (size_t)n_slots * szk::kDualTablesPerGroup * szk::kDualTableBytes;
         const size_t qbytes = (size_t)szk::kDualQueueEntries * sizeof(uint32_t);
         if (hipMalloc(&t, tbytes) == hipSuccess && hipMalloc(&g, gbytes) == hipSuccess &&

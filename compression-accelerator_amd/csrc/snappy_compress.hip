@@ -2113,7 +2113,7 @@ __device__ __forceinline__ uint32_t block_length(const uint32_t *__restrict__ in
 // tools/patches/route_mode.patch, EXPERIMENTS.md section 4.1.2.)
 __global__ __launch_bounds__(64) void reset_launch_state_kernel(uint32_t *__restrict__ select)
 {
-    if (threadIdx.x < 16)
+    if (threadIdx.x < 15)  // (select[15], the arrival counter of the sample's workgroups, is zero between launches by itself)
         select[threadIdx.x] = 0;
 }
 
@@ -2164,20 +2164,26 @@ __device__ __forceinline__ bool launch_is_mixed(const uint32_t *__restrict__ sel
     return __builtin_popcount(select[7] & 7u) >= 2;
 }
 
+// (round 5) No reset kernel in front of it: every workgroup leaves its three numbers in a slot of its own, the
+// workgroup that arrives last (a counter that it sets back to zero: the only word that has to be zero between
+// launches, and it is again when the kernel ends -- replays of a captured graph included) adds them up, writes the
+// totals with plain stores and clears the words the kernels behind it count in.
 __global__ __launch_bounds__(256) void sample_compressibility_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
     uint64_t total_len, uint32_t n_blocks, uint32_t *__restrict__ select)
 {
     __shared__ uint32_t bitmap[2048];  // 65536 bits
     __shared__ uint32_t class_bm[384];
-    __shared__ uint32_t wg_dups;
+    __shared__ uint32_t wg_dups, wg_class, wg_last;
     const uint32_t t = threadIdx.x;
     for (uint32_t i = t; i < 2048; i += 256)
         bitmap[i] = 0;
     for (uint32_t i = t; i < 384; i += 256)
         class_bm[i] = 0;
-    if (t == 0)
+    if (t == 0) {
         wg_dups = 0;
+        wg_class = 0;
+    }
     __syncthreads();
     // one block out of each of gridDim.x equal stretches of the launch, at a place inside its stretch that follows no
     // period (evenly spaced samples met only the text blocks of a launch whose every 16th block was text)
@@ -2186,27 +2192,47 @@ __global__ __launch_bounds__(256) void sample_compressibility_kernel(
     const uint32_t b = b0 + (b1 > b0 ? ((blockIdx.x * 0x9e3779b1u) >> 12) % (b1 - b0) : 0u);
     uint32_t n = block_length(in_len, total_len, in_stride, b);
     const uint8_t *in = src + (uint64_t)b * in_stride;
-    if (t < 64) {  // the cost classes the launch holds (does ordering its queue pay?)
-        const uint32_t c = block_cost_class(in, n > kMaxBlock ? 0 : n, t, class_bm);
+    n = n > kMaxBlock ? 0 : n;
+    const uint32_t n1 = n < 1024 ? n : 1024;  // text repeats >= 23 % of its shingles within 1 KiB
+    const uint32_t npos = n1 >= 4 ? n1 - 3 : 0;
+    if (t < 64) {  // wave 0: the cost class of the block (does routing / ordering the launch's blocks pay?)
+        const uint32_t c = block_cost_class(in, n, t, class_bm);
         if (t == 0)
-            atomicOr(&select[7], 1u << c);
+            wg_class = 1u << c;
+    } else {       // waves 1..3: repeats among the shingles of its first KiB
+        uint32_t dups = 0;
+        for (uint32_t p = t - 64; p < npos; p += 192) {
+            const uint32_t h = (ld32(in + p) * kHashMul) >> 16;
+            const uint32_t bit = 1u << (h & 31u);
+            dups += (atomicOr(&bitmap[h >> 5], bit) & bit) ? 1u : 0u;
+        }
+        atomicAdd(&wg_dups, dups);
     }
-    n = n > kMaxBlock ? 0 : (n < 1024 ? n : 1024);  // text repeats >= 23 % of its shingles within 1 KiB
-    const uint32_t npos = n >= 4 ? n - 3 : 0;
-    uint32_t dups = 0;
-    for (uint32_t p = t; p < npos; p += 256) {
-        const uint32_t h = (ld32(in + p) * kHashMul) >> 16;
-        const uint32_t bit = 1u << (h & 31u);
-        dups += (atomicOr(&bitmap[h >> 5], bit) & bit) ? 1u : 0u;
-    }
-    atomicAdd(&wg_dups, dups);
     __syncthreads();
     if (t == 0) {
-        atomicAdd(&select[0], wg_dups);
-        atomicAdd(&select[1], npos);
+        uint32_t *mine = select + 16 + 3 * blockIdx.x;
+        __hip_atomic_store(mine + 0, wg_dups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, npos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 2, wg_class, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t arrived = __hip_atomic_fetch_add(select + 15, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        wg_last = arrived == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (wg_last && t < 64) {  // (gridDim.x <= 64)
+        uint32_t d = 0, p = 0, c = 0;
+        if (t < gridDim.x) {
+            const uint32_t *its = select + 16 + 3 * t;
+            d = __hip_atomic_load(its + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p = __hip_atomic_load(its + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c = __hip_atomic_load(its + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        d = lane_get(wave_inclusive_sum(d), 63);
+        p = lane_get(wave_inclusive_sum(p), 63);
+        c = (ballot64((c & 1u) != 0) ? 1u : 0u) | (ballot64((c & 2u) != 0) ? 2u : 0u) | (ballot64((c & 4u) != 0) ? 4u : 0u);
+        if (t < 16)
+            select[t] = t == 0 ? d : t == 1 ? p : t == 7 ? c : 0u;  // (select[15]: the arrival counter, zero again)
     }
 }
-
 
 // ---- blocks, not launches, are routed (round 5), and the expensive ones go first (round 3)
 // A launch whose sample has met more than one cost class (launch_is_mixed) is compressed by BOTH kernels: the single
@@ -2575,11 +2601,12 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
     const bool sampled = dual_ok && dual->mode == kDualAuto;
     // blocks of a mixed launch are routed one by one (the single kernel queues what it leaves to the team kernel)
     const uint32_t queue_half = sampled && dual->kernel == kKernelTeam && dual->queue && n_blocks <= dual->queue_cap / 2 ? dual->queue_cap / 2 : 0u;
-    if (dual_ok)  // launch state := 0.  (A kernel, not hipMemsetAsync: captured into a hipGraph, the
-                  // memset node made every replay after the first a no-op.)
+    if (dual_ok && !sampled)  // a kernel named by the caller: launch state := 0.  (A kernel, not hipMemsetAsync: captured
+                              // into a hipGraph, the memset node made every replay after the first a no-op.)
         hipLaunchKernelGGL(reset_launch_state_kernel, dim3(1), dim3(64), 0, stream, dual->select);
     if (sampled) {
-        // sample -> both kernels, each checks the verdict first (graph-capture safe: no host sync)
+        // sample (it also resets the launch state) -> both kernels, each checks the verdict first (graph-capture
+        // safe: no host sync)
         const uint32_t ns = n_blocks < 64 ? n_blocks : 64;
         hipLaunchKernelGGL(sample_compressibility_kernel, dim3(ns), dim3(256), 0, stream, src, in_stride,
                            d_in_len, total_len, n_blocks, dual->select);

@@ -15,7 +15,8 @@ constexpr int32_t kStatusNoSpace = -28;    // == SZ_ENOSPC
 enum DualMode : uint32_t { kDualAuto = 0, kDualAlways = 2 };
 struct DualScratch {
     uint16_t *tables;
-    uint32_t *select;     // launch state: [0] repeats, [1] positions of the sample; [2] next entry of the block queue, [3] number of blocks in the queue
+    uint32_t *select;     // launch state (kLaunchStateBytes, zero between launches where it matters): [0] repeats, [1] positions of the sample, [7] cost classes it met;
+                          // [2] next entry of the persistent kernel's work; [5], [6] blocks of class 1, 2 in the queue; [15] arrivals of the sample's workgroups
     uint32_t *queue;      // block indices in cost order for the persistent kernels (+ one class byte per block in its upper half)
     uint32_t queue_cap;   // entries in `queue`; launches with more than half as many blocks are not ordered
     uint32_t n_slots;
@@ -25,6 +26,7 @@ struct DualScratch {
 };
 enum CompressibleKernel : uint32_t { kKernelMulti = 0, kKernelTeam = 1 };
 constexpr size_t kDualTableBytes = 16384 * 2;
+constexpr size_t kLaunchStateBytes = 1024;  // select[0..16): launch state; [16..16+3*64): the sample's per-workgroup results
 constexpr uint32_t kDualQueueEntries = 1u << 20;  // 4 MiB: 64 GiB of 64 KiB blocks per launch
 #ifndef SZ_GROUP_WAVES
 #define SZ_GROUP_WAVES 3
