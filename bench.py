@@ -129,15 +129,38 @@ def launch_ranks(n, script, script_args, env=None, timeout=None):
     return p.returncode, line, out, err
 
 
-def layout_fields(gathered, offsets, local_lens, rank, blocks_per_rank):
-    """What rank 0 reports about the one collective of the path: how many ranks' lengths arrived, and
-    whether the gathered layout is the one every rank would pack with (ends at the total; this
-    rank's slice of it is this rank's own lengths).  Tensors on any device."""
+def verify_gather(gathered, offsets, local_lens, rank, world, n_total, group_is_up):
+    """What is reported about the one collective of the path -- checked, not inferred from a tensor's size.  Outside the
+    timed region every rank publishes a tag of what it HAD (its rank, its number of blocks, the sum and a
+    position-weighted checksum of its own lengths; one more tiny all_gather); every rank then compares each tag with the
+    slice of that rank in the lengths it RECEIVED in the timed step.  `rccl_ranks_seen` = ranks whose slice arrived as
+    sent (must be `world`), `gathered_layout_ok` = all of them did, the layout ends at the total, and this rank's
+    slice is its own lengths.  Tensors on any device; with one rank (no process group) the tag is compared locally."""
     import torch
-    n = int(gathered.numel())
-    ok = (int(offsets[-1].item()) == int(gathered.to(torch.int64).sum().item())
-          and bool(torch.equal(gathered[rank * blocks_per_rank:(rank + 1) * blocks_per_rank], local_lens)))
-    return {"rccl_ranks_seen": n // blocks_per_rank if blocks_per_rank else 0, "gathered_layout_ok": ok}
+    from compression_accelerator_amd import sharding as shard
+
+    def tag_of(lens, r):
+        v = lens.to(torch.int64)
+        w = torch.arange(1, v.numel() + 1, dtype=torch.int64, device=v.device)
+        return [r, int(v.numel()), int(v.sum().item()), int(((v * w).sum() % 2305843009213693951).item())]
+
+    mine = torch.tensor(tag_of(local_lens, rank), dtype=torch.int64, device=gathered.device)
+    if group_is_up and world > 1:
+        import torch.distributed as dist
+        tags = torch.empty(4 * world, dtype=torch.int64, device=gathered.device)
+        dist.all_gather_into_tensor(tags, mine)
+        tags = tags.reshape(world, 4).cpu().tolist()
+    else:
+        tags = [mine.cpu().tolist()]
+    seen = 0
+    for r in range(world):
+        b, e = shard.shard_range(n_total, r, world)
+        seen += 1 if tags[r] == tag_of(gathered[b:e], r) else 0
+    b, e = shard.shard_range(n_total, rank, world)
+    ok = (seen == world and int(gathered.numel()) == n_total
+          and int(offsets[-1].item()) == int(gathered.to(torch.int64).sum().item())
+          and bool(torch.equal(gathered[b:e], local_lens)))
+    return {"rccl_ranks_seen": seen, "gathered_layout_ok": ok}
 
 
 # ------------------------------------------------------------------------------- inputs (on device)
@@ -201,9 +224,8 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
         offs = [torch.empty(n_total + 1, dtype=torch.int64, device=device) for _ in range(2)]
     consumed = [None, None]
     hev = None
-    # which kernel does this workload's work (the library enqueues both when it samples; the other one exits at once)
-    forced = os.environ.get("SZ_KERNEL")
-    single_is_dominant = forced == "single" or (forced not in ("team", "dual") and kind == "c3")
+    # (which kernel does a workload's work is the library's choice -- per launch from a sample, per block in a mixed
+    # launch --: all four events go to every sampled step and the longer pair is the dominant kernel)
 
     def step(i, e0=None, e1=None):
         k = i & 1
@@ -216,10 +238,7 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
         if sampled_step:
             e0.record()  # same stream as the kernel launch (torch's current stream)
             four = hev.ev[i - warmup]
-            if single_is_dominant:  # events around the dominant kernel, recorded by the library
-                P.profile_next_launch(four[0], four[1], None, None)
-            else:
-                P.profile_next_launch(None, None, four[2], four[3])
+            P.profile_next_launch(four[0], four[1], four[2], four[3])  # events around both compress kernels, recorded by the library
         P.compress_blocks(src, BLOCK, n_blocks, dst=dst, out_len=out_lens[k], varint=True)
         if sampled_step:
             e1.record()
@@ -255,18 +274,23 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # (reported, not asserted: a bench line beats a traceback)
-        layout = layout_fields(gathered[last], offs[last], out_lens[last], dist.get_rank(), n_blocks)
+        layout = verify_gather(gathered[last], offs[last], out_lens[last], dist.get_rank(), world, n_total, True)
     out_len = out_lens[last]
     sampled = [i for i in range(steps) if i % EVENT_EVERY == 0]
     call_ms = [ev[i][0].elapsed_time(ev[i][1]) for i in sampled]  # the whole call: reset + sample + compress kernels + ordering kernels
     # the dominant kernel alone (HIP events recorded by the library around its launch, on the launch's stream)
-    kernel_ms = []
+    single_ms = [hev.ms(i, False) for i in sampled]
+    multi_ms = [hev.ms(i, True) for i in sampled]
+    hev.close()
+    mean_of = lambda v: (sum(x for x in v if x is not None) / max(1, sum(1 for x in v if x is not None))) if any(x is not None for x in v) else 0.0
+    single_is_dominant = mean_of(single_ms) >= mean_of(multi_ms)
     kernel_name = "szk::compress_blocks_kernel" if single_is_dominant else (
         "szk::compress_blocks_team_kernel" if os.environ.get("SZ_KERNEL") != "dual" else "szk::compress_blocks_dual_kernel")
-    for j, i in enumerate(sampled):
-        k_ms = hev.ms(i, not single_is_dominant)
-        kernel_ms.append(k_ms if k_ms is not None else call_ms[j])  # (the kernel was not launched in this mode: the call)
-    hev.close()
+    kernel_ms = []
+    for j in range(len(sampled)):
+        k_ms = single_ms[j] if single_is_dominant else multi_ms[j]
+        kernel_ms.append(k_ms if k_ms is not None else call_ms[j])  # (no kernel recorded its events: the call)
+    other_ms = mean_of(multi_ms if single_is_dominant else single_ms)  # the other compress kernel of the call (it exits at once, or takes its blocks of a mixed launch)
 
     # ---- checks, outside the timed region: EVERY block against the oracle (bytes and lengths)
     lens = out_len.cpu().numpy().astype(np.int64)
@@ -286,7 +310,7 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
         dec = {"ms": e0.elapsed_time(e1), "round_trip": bool(torch.equal(back, src)) and int(status.abs().sum().item()) == 0}
         del back
     del src, dst
-    return {"elapsed_s": elapsed, "kernel_ms": kernel_ms, "call_ms": call_ms, "kernel_name": kernel_name,
+    return {"elapsed_s": elapsed, "kernel_ms": kernel_ms, "call_ms": call_ms, "kernel_name": kernel_name, "other_kernel_ms": other_ms,
             "in_bytes": n_blocks * BLOCK, "out_bytes": out_bytes,
             "blocks_differing_from_oracle": bad, "first_bad_block": first_bad, "n_blocks": n_blocks,
             "decompress": dec, "layout": layout}
@@ -490,6 +514,18 @@ def _time_libsnappy(lib, src, sample_blocks, cores, budget_s):
                     "its bytes equal the oracle's only if it is 1.1.8"}
 
 
+def load_pmc(kind, n_blocks):
+    """The committed summary of the rocprofv3 --pmc passes of this workload at this size (profiles/pmc_<kind>_<blocks>.json,
+    written by profiles/pmc_summary.py from the passes tools/profile_r05.sh runs), or {}."""
+    path = os.path.join(ROOT, "profiles", "pmc_%s_%d.json" % (kind, n_blocks))
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        d = json.load(f)
+    d["_source"] = "profiles/%s (rocprofv3 --pmc passes, committed; not re-measured in this run)" % os.path.basename(path)
+    return d
+
+
 # ----------------------------------------------------------------------------------------- one rank
 
 def rank_main(args):
@@ -531,10 +567,22 @@ def rank_main(args):
             xsteps = 10
             r = run_workload(P, kind, rank * nb, nb, xsteps, 2, device, dist_on, decompress=True)
             k_ms = float(np.mean(r["kernel_ms"]))
+            algo = r["in_bytes"] + r["out_bytes"] + 4 * nb  # algorithmic bytes per launch: input read once + output written once + lengths
+            pmc_w = load_pmc(kind, nb)
             extras[kind] = {"input_GBps": round(r["in_bytes"] * world * xsteps / r["elapsed_s"] / 1e9, 2), "steps": xsteps,
                             "kernel_ms": round(k_ms, 3), "kernel": r["kernel_name"], "blocks_per_gpu": nb,
                             "compression_ratio": round(r["in_bytes"] / r["out_bytes"], 4),
                             "hbm_frac_in_plus_out": round((r["in_bytes"] + r["out_bytes"]) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "roofline": {"bound": "hbm", "kernel": r["kernel_name"], "kernel_ms_avg": round(k_ms, 4),
+                                         "other_compress_kernel_ms_avg": round(r["other_kernel_ms"], 4),
+                                         "call_ms_avg": round(float(np.mean(r["call_ms"])), 4),
+                                         "algorithmic_bytes_per_launch": algo,
+                                         "achieved": round(algo / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                         "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                         "traffic": int(pmc_w["hbm_traffic_bytes_per_launch"]) if pmc_w.get("hbm_traffic_bytes_per_launch") else None,
+                                         "traffic_source": pmc_w.get("_source"),
+                                         "lds_bank_conflict_frac": pmc_w.get("lds_bank_conflict_frac"),
+                                         "resident_waves_per_simd": pmc_w.get("resident_waves_per_simd")},
                             "blocks_differing_from_oracle": r["blocks_differing_from_oracle"],
                             "gpu_decompress_GBps": round(r["in_bytes"] / (r["decompress"]["ms"] * 1e-3) / 1e9, 2),
                             "gpu_round_trip": r["decompress"]["round_trip"]}
@@ -559,13 +607,9 @@ def rank_main(args):
         k_ms = float(np.mean(main_res["kernel_ms"]))
         algo_bytes = main_res["in_bytes"] + main_res["out_bytes"] + 4 * B  # per launch (this rank)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/pmc_summary.py)
-        pmc = {}
+        pmc = load_pmc(args.workload, B)  # HBM bytes per launch etc. from the committed PMC passes (profiles/pmc_summary.py)
         pmc_path = os.path.join(ROOT, "profiles", "pmc_%s_%d.json" % (args.workload, B))
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc = json.load(f)
-            traffic = pmc.get("hbm_traffic_bytes_per_launch")
+        traffic = pmc.get("hbm_traffic_bytes_per_launch")
         roof = copy_roof(main_res["in_bytes"], device) if world == 1 else None
         line = {
             "metric": "snappy_compress_input_GBps_64KiB_blocks",
@@ -617,9 +661,21 @@ def rank_main(args):
                         extras[kind]["cpu_baseline"]["system_libsnappy"] = t["system_libsnappy"]
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()
+    # The line is out; a run whose blocks differ from the oracle, or whose length gather did not bring every rank's
+    # lengths as sent, FAILS (exit status, after the line: a bench line beats a traceback, but not a green light)
+    verdict = 0
+    if bad_all != 0:
+        verdict = 3
+    if dist_on and rank == 0:
+        views = [main_res["layout"]] + [{k: v[k] for k in ("rccl_ranks_seen", "gathered_layout_ok")} for v in extras.values() if "rccl_ranks_seen" in v]
+        if any(v is None or v["rccl_ranks_seen"] != world or not v["gathered_layout_ok"] for v in views):
+            verdict = 4
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if verdict:
+        print("bench.py: FAILED (%s)" % ("blocks differ from the oracle" if verdict == 3 else "the length gather did not deliver every rank's lengths"), file=sys.stderr)
+        raise SystemExit(verdict)
 
 
 def main():

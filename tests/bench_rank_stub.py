@@ -20,20 +20,22 @@ from pkg_loader import load_package
 
 
 def main():
-    blocks_per_rank = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    n_total = int(sys.argv[1]) if len(sys.argv) > 1 else 12  # blocks of the whole job (ragged over the ranks if it does not divide)
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
     load_package()
     from compression_accelerator_amd import sharding
     dist.init_process_group("gloo")
     data = fuzzgen.corpus("mtg")
-    first = rank * blocks_per_rank
-    lens = torch.tensor([len(oracle_lib.raw_compress(data[(first + k) * 65536:(first + k + 1) * 65536]))
-                         for k in range(blocks_per_rank)], dtype=torch.int32)
-    n_total = blocks_per_rank * world
+    first, end = sharding.shard_range(n_total, rank, world)
+    lens = torch.tensor([len(oracle_lib.raw_compress(data[k * 65536:(k + 1) * 65536])) for k in range(first, end)], dtype=torch.int32)
+    if os.environ.get("SZ_STUB_DROP_RANK") == str(rank):  # fault injection: this rank's lengths do not arrive as sent
+        sent = torch.zeros_like(lens)
+    else:
+        sent = lens
     gathered = torch.empty(n_total, dtype=torch.int32)
     offs = torch.empty(n_total + 1, dtype=torch.int64)
-    sharding.gather_lengths(lens, n_total, out=gathered, offsets=offs)
-    fields = bench.layout_fields(gathered, offs, lens, rank, blocks_per_rank)
+    sharding.gather_lengths(sent, n_total, out=gathered, offsets=offs)
+    fields = bench.verify_gather(gathered, offs, lens, rank, world, n_total, True)
     ok = torch.tensor([1 if fields["gathered_layout_ok"] else 0])
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rank == 0:

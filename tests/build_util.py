@@ -20,3 +20,12 @@ def cc(src, out, force_shim=False):
 def cxx(src, out):
     subprocess.check_call(["g++", "-std=c++11", "-I" + INC, src, "-o", out] + LINK, stderr=subprocess.DEVNULL)
     return out
+
+
+def cc_rccl(src, out):
+    """A plain-C caller that also talks to the HIP runtime and to librccl directly (drivers/shard_compress.c)."""
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.check_call(["gcc", "-std=gnu99", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-I" + INC,
+                           src, "-o", out] + LINK + ["-L" + os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64",
+                                                     "-Wl,-rpath," + os.path.join(rocm, "lib")], stderr=subprocess.DEVNULL)
+    return out

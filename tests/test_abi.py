@@ -238,3 +238,12 @@ def test_parse_state_of_the_compress_kernels_is_provably_wave_uniform(tmp_path):
         div = [l.strip()[:120] for l in fn.splitlines() if state.search(l)]
         assert not div, "%s: parse state the compiler cannot prove uniform:\n%s" % (name, "\n".join(div[:10]))
     assert seen == 4  # single, multi-wave, team, small-blocks
+
+
+def test_the_rccl_c_caller_builds_against_the_abi(tmp_path):
+    """drivers/shard_compress.c (hipSetDevice, sz_shard_range, sz_compress_blocks_hip, ncclAllGather from librccl,
+    sz_stream_offsets) compiles as plain C and links against include/ + libsnappy_hip.so + librccl; it runs in the
+    GPU tests (tests/test_gpu_dist.py).  Without arguments it only prints its usage."""
+    exe = build_util.cc_rccl(os.path.join(build_util.DRIVERS, "shard_compress.c"), str(tmp_path / "shard_compress"))
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 2 and b"usage" in r.stderr

@@ -47,6 +47,58 @@ def _device_count():
     return torch.cuda.device_count()
 
 
+def _run_c_ranks(tmp_path, world, data):
+    """drivers/shard_compress.c, `world` processes (one per GPU): the path's sequence in plain C with librccl."""
+    import subprocess
+    import build_util
+    exe = build_util.cc_rccl(os.path.join(build_util.DRIVERS, "shard_compress.c"), str(tmp_path / "shard_compress"))
+    inp = tmp_path / "job.bin"
+    inp.write_bytes(data)
+    idf = str(tmp_path / "rccl.id")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([exe, str(inp), str(world), str(r), idf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+             for r in range(world)]
+    outs = []
+    for r, p in enumerate(procs):
+        try:
+            out, err = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, "rank %d of the C caller failed (rc %d)\n%s" % (r, p.returncode, err.decode()[-3000:])
+        outs.append(json.loads(out.decode().strip().splitlines()[-1]))
+    return outs
+
+
+def _check_c_ranks(outs, world, data):
+    n_blocks = (len(data) + 65535) // 65536
+    want = [len(oracle_lib.compress_fragment(data[i * 65536:(i + 1) * 65536])) for i in range(n_blocks)]  # bodies (flags = 0)
+    hdr = len(oracle_lib.raw_compress(data)) - sum(want)  # the stream's preamble
+    for r, o in enumerate(outs):
+        assert (o["rank"], o["world"], o["n_blocks"]) == (r, world, n_blocks)
+        assert o["rccl_ranks_seen"] == world and o["own_slice_ok"] and o["layout_ok"]
+        assert o["lens"] == want, "rank %d: gathered lengths differ from the oracle's" % r
+        assert o["stream_bytes"] == hdr + sum(want) == len(oracle_lib.raw_compress(data))
+    assert [o["begin"] for o in outs] == [outs[k - 1]["end"] if k else 0 for k in range(world)] and outs[-1]["end"] == n_blocks
+
+
+def test_c_caller_with_rccl_directly_one_rank(tmp_path):
+    """hipSetDevice, sz_shard_range, sz_compress_blocks_hip, ncclAllGather FROM LIBRCCL, sz_stream_offsets
+    -- the sequence of INTEGRATION.md section 6 compiled and run, one rank; lengths and layout against the oracle."""
+    import fuzzgen
+    data = fuzzgen.corpus("mtg")[:65536 * 37 + 1234]  # a ragged job
+    _check_c_ranks(_run_c_ranks(tmp_path, 1, data), 1, data)
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs")
+def test_c_caller_with_rccl_directly_two_ranks(tmp_path):
+    import fuzzgen
+    data = fuzzgen.corpus("mtg")[:65536 * 37 + 1234]  # 38 blocks: 19 + 19; the second shard ends ragged
+    _check_c_ranks(_run_c_ranks(tmp_path, 2, data), 2, data)
+
+
 @pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs")
 def test_two_ranks_over_rccl_and_the_c_abi_on_device_one():
     r = _run_bench(2, [])

@@ -146,7 +146,7 @@ def test_bench_launcher_starts_the_ranks_itself():
     stub = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_rank_stub.py")
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
-    rc, line, out, err = bench.launch_ranks(2, stub, ["5"], env=env, timeout=300)
+    rc, line, out, err = bench.launch_ranks(2, stub, ["10"], env=env, timeout=300)
     assert rc == 0, err[-2000:]
     assert line is not None, out[-2000:]
     r = json.loads(line)
@@ -156,6 +156,34 @@ def test_bench_launcher_starts_the_ranks_itself():
     # a failing rank is reported through the exit code, not swallowed
     rc2, line2, _, _ = bench.launch_ranks(2, stub, ["not-a-number"], env=env, timeout=300)
     assert rc2 != 0 and line2 is None
+
+
+def test_eight_ranks_ragged_total_and_a_rank_whose_lengths_do_not_arrive():
+    """The first N = 8 run on hardware must verify itself: world_size 8 over gloo, a total that
+    does not divide (43 blocks: shards of 6, 6, 6, 5, 5, 5, 5, 5), `rccl_ranks_seen` counted from per-rank tags that
+    every rank publishes and every rank checks against the slice it received, the per-rank slices and the layout
+    against the oracle.  Then the same with one rank's lengths zeroed on the way: seen == 7, layout not ok."""
+    import json
+    import bench
+    load_package()
+    from compression_accelerator_amd import sharding
+    stub = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_rank_stub.py")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["OMP_NUM_THREADS"] = "1"
+    rc, line, out, err = bench.launch_ranks(8, stub, ["43"], env=env, timeout=600)
+    assert rc == 0 and line is not None, (out[-2000:], err[-2000:])
+    r = json.loads(line)
+    assert r["n_gpus"] == 8 and r["rccl_ranks_seen"] == 8 and r["gathered_layout_ok"] is True
+    want = [len(oracle_lib.raw_compress(x)) for x in _blocks(43)]
+    assert r["lens"] == want and r["total"] == sum(want)
+    sizes = [e - b for b, e in (sharding.shard_range(43, k, 8) for k in range(8))]
+    assert sizes == [6, 6, 6, 5, 5, 5, 5, 5]
+    env["SZ_STUB_DROP_RANK"] = "5"
+    rc, line, out, err = bench.launch_ranks(8, stub, ["43"], env=env, timeout=600)
+    assert rc == 0 and line is not None, (out[-2000:], err[-2000:])
+    r = json.loads(line)
+    assert r["rccl_ranks_seen"] == 7 and r["gathered_layout_ok"] is False
 
 
 def test_bench_arguments_default_to_one_gpu_and_short_runs():
