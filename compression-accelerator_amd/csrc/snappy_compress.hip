@@ -1334,6 +1334,41 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     Hraw = (Hraw & ~sel) | ballot64(on && hit);
                 };
 
+                // Where the parse goes from each lane, with what the exit of a visit needs to know about the last jump
+                // beside it, so that the walk's last v_readlane IS the exit state (the team path's form, round 5 here too):
+                //   X: bits 0..5 target lane (next hit at or after this lane, then past its match), bit 6 the jump leaves the
+                //      tile (bits 0..5 then name the lane itself), bit 7 no hit from here on (the scan stays open), bit 8 that
+                //      hit's match reaches 32 bytes (long), bits 10..15 lane of that hit, bits 16..23 where the parse stands
+                //      afterwards relative to the tile;
+                //   Y: the state a visit that ends with this lane's jump hands on (position, chain flag, "copy ends with the
+                //      tile", scan index); Z: the pending literal's start.
+                constexpr bool kFastX = true;
+                uint32_t X = 0, Y = 0, Z = 0;
+                uint64_t farmask = 0;
+                auto jumps = [&]() {
+                    const uint64_t tl = Hraw >> lane;
+                    uint32_t dlo, dhi;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(dlo) : "v"((uint32_t)tl));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(dhi) : "v"((uint32_t)(tl >> 32)));
+                    const uint32_t dist = umin3(dlo, dhi | 32u, 64u);  // 64: no hit from here on
+                    const uint32_t nh_l = lane + dist;
+                    const uint32_t m_nh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nh_l << 2), (int)tmlw);
+                    const bool open = dist >= 64u;
+                    const bool lng = !open && m_nh == 64u;
+                    const uint32_t sum = nh_l + m_nh;
+                    uint32_t tgt = sum > lane ? sum : lane + 1;  // (always so for a hit: ml >= 4; keeps the walk finite whatever memory holds)
+                    tgt = (open || tgt > 64u) ? 64u : tgt;
+                    const uint32_t p2off = open ? 64u : (lng ? nh_l : sum);
+                    const uint32_t base_ = t << 6;
+                    X = (tgt >= 64u ? lane | 64u : tgt) | (open ? 1u << 7 : 0u) | (lng ? 1u << 8 : 0u) | ((nh_l & 63u) << 10) |
+                        ((p2off & 0xffu) << 16);
+                    Y = (base_ + p2off) | (open ? 0u : 1u << 17) | ((!open && !lng && sum == 64u) ? 1u << 18 : 0u) |
+                        (open ? (63u - lane) << 19 : 0u);
+                    Z = open ? base_ + lane : base_ + p2off;
+                    // lanes from which a scan could reach probe 32 inside the tile (32 hit-free lanes in a row)
+                    farmask = ballot64(dist >= run32);
+                };
+
                 PROF_LAP(14);
                 auto enter_head = [&](uint32_t P2v, uint32_t e2v) {  // bytes, hashes, lookups, candidate loads of P2v's tile
                     head(P2v >> 6);
@@ -1480,75 +1515,67 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         head_loads();
                     }
                     PROF_LAP(25);
+                    if (kFastX)
+                        jumps();
                     for (;;) {  // ============================================ visits of this tile
                         // (every visit ends beyond its entry lane, every tile beyond the one before: no trip count)
                         MARK("visit_top");
-                        const uint64_t Hm = Hraw & ~below63(e);
-                        // ---- where the parse goes from each lane: to the next hit at or after it, then
-                        // past that hit's match (64 = out of the tile; a match that reaches 32 bytes ends
-                        // the visit)
-                        const uint64_t tl = Hm >> lane;
-                        uint32_t dlo, dhi;
-                        asm("v_ffbl_b32 %0, %1" : "=v"(dlo) : "v"((uint32_t)tl));
-                        asm("v_ffbl_b32 %0, %1" : "=v"(dhi) : "v"((uint32_t)(tl >> 32)));
-                        const uint32_t dist = umin3(dlo, dhi | 32u, 64u);  // 64: no hit from here on
-                        const uint32_t nh_l = lane + dist;
-                        const uint32_t m_nh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nh_l << 2), (int)tmlw);
-                        uint32_t vJ = nh_l + m_nh;
-                        vJ = vJ > lane ? vJ : lane + 1;  // (always so for a hit: ml >= 4; keeps the walk finite whatever memory holds)
-                        vJ = vJ < 64u ? vJ : 64u;
-                        // ---- states left to the general code: a scan could reach probe 32 (32 hit-free
-                        // lanes in a row, or the misses carried in plus those before the first hit)
-                        const uint64_t far = ballot64(dist >= run32) & ~below63(e);
-                        const uint32_t lead = ctz64(Hm | (1ull << 63)) - e;
-                        const uint32_t lead_bad = (c_in ^ 1u) & (sc_in + lead > 31 ? 1u : 0u);
-                        if (__builtin_expect((far != 0) | (lead_bad != 0), 0)) {  // (P2, chain2, sc2 are this very state: base + e, c_in, sc_in)
-                            hold_fast = true;
-                            quit = 1;
-                            break;
+                        const uint64_t keep = ~below63(e);  // the lanes the parse can still reach
+                        const uint64_t Hm = Hraw & keep;
+                        // ---- where the parse goes from each lane (X, Y, Z: made once per tile and after a patch), and the
+                        // states left to the general code: a scan could reach probe 32 (32 hit-free lanes in a row, or the
+                        // misses carried in plus those before the first hit)
+                        uint32_t x = lane_get(X, e);
+                        {
+                            const uint32_t lead = (x & 0x80u) ? 63u - e : ((x >> 10) & 63u) - e;
+                            const uint32_t lead_bad = (c_in ^ 1u) & ((31u - (sc_in + lead)) >> 31);  // sc_in + lead > 31
+                            const uint64_t far = farmask & keep;
+                            if (__builtin_expect(((uint32_t)far | (uint32_t)(far >> 32) | lead_bad) != 0, 0)) {  // (P2, chain2, sc2 are this very state: base + e, c_in, sc_in)
+                                hold_fast = true;
+                                quit = 1;
+                                break;
+                            }
                         }
                         PROF_LAP(15);
                         MARK("walk_loop");
-                        // ---- the serial part: one v_readlane per element
-                        uint64_t S = 0;
-                        uint32_t jj = e;
+                        // ---- the serial part: one v_readlane per element; the last one is the exit state
+                        // (four steps at a time, no branch in between: s_lshl_b64 and v_readlane use bits 0..5 of their
+                        // lane operand; a lane whose jump leaves the tile points at itself with bit 6 set, so steps past
+                        // the end change nothing)
+                        uint64_t S = 1ull << e;
                         do {
-                            S |= 1ull << jj;
-                            jj = lane_get(vJ, jj);
-                        } while (jj < 64);
+                            uint64_t bit;
+                            asm volatile(
+                                "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
+                                "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
+                                "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1\n\t"
+                                "s_lshl_b64 %2, 1, %1\n\ts_or_b64 %0, %0, %2\n\ts_nop 1\n\tv_readlane_b32 %1, %3, %1"
+                                : "+s"(S), "+s"(x), "=&s"(bit)
+                                : "v"(X)
+                                : "scc");  // (s_lshl_b64 and s_or_b64 write SCC)
+                        } while (!(x & 64u));
                         PROF_LAP(16);
                         MARK("exit_commit");
-                        // ---- exit state, commit, check.  Common case first (no two inserted lanes share
-                        // a bucket: lim = 64); a shared bucket repeats the exit computation for lim = cut.
+                        // ---- exit state, commit, check.  Common case first (no two inserted lanes share a bucket); a
+                        // shared bucket repeats the exit computation for a visit that ends before lane `cut`.
+                        const uint32_t s_l = x & 63u;  // the last start: the lane whose jump left the tile
                         uint64_t V, Hp, C;
                         uint32_t ll, emit2;
-                        // (selects of wave-uniform integers, no branches: the compiler then keeps all of
-                        // it in scalar registers without copies where branch arms would meet)
-                        auto exit_for = [&](uint32_t lim) {
-                            const uint64_t bl = lanes_below(lim);
-                            const uint64_t Hm_t = Hm & bl, Sx = S & bl;
-                            const uint32_t s_l = 63u - (uint32_t)__builtin_clzll(Sx);  // (lane e is in Sx)
-                            const uint64_t Hx = Hm_t >> s_l;
-                            const uint32_t open = Hx == 0 ? 1u : 0u;  // the literal / scan is still open at lim
-                            Hp = Hm_t & ~(Hm_t - Sx);  // first hit of every segment [start, next start)
-                            const uint64_t bitlim = lim < 64 ? 1ull << lim : 0ull;
-                            V = (((Hp << 1) | (open ? bitlim : 0ull)) - Sx) & bl;
-                            const uint32_t jx = (s_l + ctz64(Hx | (1ull << 63))) & 63u;  // the last hit on the path
-                            const uint32_t mj = lane_get(tmlw, jx);
-                            const uint32_t carried = (Sx == (1ull << e) ? 1u : 0u) & (c_in ^ 1u);
-                            const uint32_t is_long = (open ^ 1u) & (mj == 64 ? 1u : 0u);
-                            const uint32_t pend = base + jx + mj;  // where the last copy ends
-                            chain2 = open ^ 1u;
-                            ll = is_long ? jx : 64u;  // (the long match is finished at (A))
-                            P2 = open ? base + lim : (is_long ? base + jx : pend);
-                            sc2 = open ? (carried ? sc_in + lim - e : lim - s_l - 1) : 0u;
-                            emit2 = open ? (carried ? next_emit : base + s_l) : pend;
-                            // the copy ends with the tile: its last byte is the next P-1
-                            pm1_done = (open ^ 1u) & (is_long ^ 1u) & (lim == 64 ? 1u : 0u) & (jx + mj == 64 ? 1u : 0u);
-                            const uint64_t Ins = ((Sx & ~(1ull << e)) >> 1) | ((uint64_t)pm1_done << 63);  // the lane before each chain probe
-                            C = V | Ins;
-                        };
-                        exit_for(64);
+                        {
+                            const uint32_t y = lane_get(Y, s_l), z = lane_get(Z, s_l);
+                            const uint32_t open = (x >> 7) & 1u;
+                            // the scan carried in found nothing: (s_l == e) as an integer, ((s_l ^ e) - 1) >> 31
+                            const uint32_t carried = (((s_l ^ e) - 1u) >> 31) & (c_in ^ 1u) & open;
+                            P2 = y & 0x1ffffu;
+                            chain2 = (y >> 17) & 1u;
+                            pm1_done = (y >> 18) & 1u;
+                            sc2 = carried ? sc_in + 64u - e : (y >> 19) & 63u;
+                            emit2 = carried ? next_emit : z;
+                            ll = (x & 0x100u) ? (x >> 10) & 63u : 64u;
+                            Hp = Hm & ~(Hm - S);  // first hit of every segment [start, next start)
+                            V = (Hp << 1) - S;    // [start, hit] of every segment; an open last one runs to lane 63
+                            C = V | ((S & ~(1ull << e)) >> 1) | ((uint64_t)pm1_done << 63);  // + the lane before each chain probe
+                        }
                         {
                             const bool inC = __builtin_amdgcn_inverse_ballot_w64(C);
                             uint64_t L;
@@ -1590,8 +1617,27 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                 const bool no_cut = !Tab::kInLds && cut >= 64;
                                 const bool bad_cut = !no_cut && (cut <= e || cut >= 64);
                                 poisoned = poisoned || bad_cut;
-                                if (!no_cut)
-                                    exit_for(bad_cut ? e + 1 : cut);
+                                if (!no_cut) {
+                                    // the same exit for a visit that ends before lane `cut`: the last start below it, and either
+                                    // its hit lies below the cut too (then nothing changes for it) or the scan is open there
+                                    cut = bad_cut ? e + 1 : cut;
+                                    const uint64_t bl = below63(cut);
+                                    const uint64_t Sx = S & bl, Hm_t = Hm & bl;
+                                    const uint32_t sl = 63u - (uint32_t)__builtin_clzll(Sx | 1ull);
+                                    const uint32_t xs = lane_get(X, sl);
+                                    const uint32_t open = ((xs >> 7) & 1u) | ((((xs >> 10) & 63u) - cut) >> 31 ^ 1u);  // no hit, or it lies at or past the cut
+                                    const uint32_t carried = (((sl ^ e) - 1u) >> 31) & (c_in ^ 1u) & open;
+                                    const uint32_t y = lane_get(Y, sl), z = lane_get(Z, sl);
+                                    P2 = open ? base + cut : y & 0x1ffffu;
+                                    chain2 = open ^ 1u;
+                                    pm1_done = 0;
+                                    sc2 = open ? (carried ? sc_in + cut - e : cut - sl - 1u) : 0u;
+                                    emit2 = open ? (carried ? next_emit : base + sl) : z;
+                                    ll = ((open ^ 1u) & (xs >> 8) & 1u) ? (xs >> 10) & 63u : 64u;
+                                    Hp = Hm_t & ~(Hm_t - Sx);
+                                    V = (((Hp << 1) | (open ? 1ull << cut : 0ull)) - Sx) & bl;
+                                    C = V | ((Sx & ~(1ull << e)) >> 1);
+                                }
                                 if (__builtin_amdgcn_inverse_ballot_w64(C))
                                     tab.put(th, pos);  // lanes below a cut share no bucket
                                 UNIFORM_JOIN();
@@ -1618,8 +1664,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         asm volatile("" ::: "memory");
                         const uint32_t cn = tab.get(th);
                         const uint64_t st = ballot64(cn != tcand) & ~below63(e2s);
-                        if (st)
+                        if (st) {
                             patch(st, cn);
+                            jumps();
+                        }
                         PROF_LAPV(23);
                         e = e2s;
                         c_in = chain2;
