@@ -44,6 +44,9 @@ namespace szk {
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxTable = 16384u;
 static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
+#ifndef SZ_NT_GATHER
+#define SZ_NT_GATHER 0
+#endif
 #ifndef SZ_SPEC_MODE
 #define SZ_SPEC_MODE 0  // head of the next tile issued ahead of the walk: 0 never (measured best), 1 waves with the table in LDS, 2 all
 #endif
@@ -1309,8 +1312,16 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     tn = tt;
                 };
                 auto head_loads = [&]() {
+#if SZ_NT_GATHER
+                    if (!Tab::kInLds) {
+                        nc = ld128_nt(in + ncand);
+                        nc2 = ld128_nt(in + ncand + 16);
+                    } else
+#endif
+                    {
                     nc = ld128(in + ncand);  // ncand < pos, pos + 32 <= n here
                     nc2 = ld128(in + ncand + 16);
+                    }
                 };
                 // candidates changed for the lanes in `sel` (their bucket was written after their lookup):
                 // both strings again, hit bit and match length merged in
@@ -2180,21 +2191,38 @@ __device__ __forceinline__ uint32_t block_cost_class(const uint8_t *__restrict__
 {
     const uint32_t n1 = n < 1024 ? n : 1024;
     const uint32_t npos = n1 >= 4 ? n1 - 3 : 0;
-    uint32_t dups = 0;
-    for (uint32_t p = lane; p < npos; p += 64) {
-        const uint32_t h = (ld32(in + p) * kHashMul) >> 19;  // 13 bits
-        const uint32_t bit = 1u << (h & 31u);
-        dups += (atomicOr(&bitmap[h >> 5], bit) & bit) ? 1u : 0u;
+    // (every load of the block is requested before the first result is used: one round trip to memory, not two or
+    // eighteen -- in a routed launch this runs in front of every block of the single kernel, one wave per SIMD)
+    uint32_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t p = lane + 64u * k;
+        v[k] = p < npos ? ld32(in + p) : 0u;
     }
-    uint32_t fresh = 0, nsamp = 0;
-    if (n >= 4096) {
-        // (a power-of-two stride for a full block: data that repeats with a period that divides a multiple of 512
-        // -- pages, records, a pattern tiled over the block -- shows few distinct samples)
-        const uint32_t stride = n >> 7;  // 128 samples over the block; the last one ends at 127 n / 128 + 8 <= n
-        nsamp = 128;
-        for (uint32_t k = lane; k < 128; k += 64) {
-            const uint64_t v = ld64(in + k * stride);
-            const uint32_t h = ((uint32_t)((v * 0x9e3779b97f4a7c15ull) >> 40)) & 4095u;
+    uint64_t far[2] = {0, 0};
+    const uint32_t nsamp = n >= 4096 ? 128u : 0u;
+    // (a power-of-two stride for a full block: data that repeats with a period that divides a multiple of 512
+    // -- pages, records, a pattern tiled over the block -- shows few distinct samples)
+    const uint32_t stride = n >> 7;  // 128 samples over the block; the last one ends at 127 n / 128 + 8 <= n
+    if (nsamp) {
+        far[0] = ld64(in + lane * stride);
+        far[1] = ld64(in + (lane + 64u) * stride);
+    }
+    uint32_t dups = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t p = lane + 64u * k;
+        if (p < npos) {
+            const uint32_t h = (v[k] * kHashMul) >> 19;  // 13 bits
+            const uint32_t bit = 1u << (h & 31u);
+            dups += (atomicOr(&bitmap[h >> 5], bit) & bit) ? 1u : 0u;
+        }
+    }
+    uint32_t fresh = 0;
+    if (nsamp) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t h = ((uint32_t)((far[k] * 0x9e3779b97f4a7c15ull) >> 40)) & 4095u;
             const uint32_t bit = 1u << (h & 31u);
             fresh += (atomicOr(&bitmap[256 + (h >> 5)], bit) & bit) ? 0u : 1u;
         }
@@ -2315,8 +2343,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (b >= n_blocks)
         return;
     const bool routed = select && launch_is_routed(select, queue_half);
-    if (select && !routed && prefers_dual(select))  // auto mode, one kind of block: the sampled data is compressible, the team kernel runs
+    if (select && !routed && prefers_dual(select)) {  // auto mode, one kind of block: the sampled data is compressible, the team kernel runs
+        // (every block a persistent kernel is to take starts out POISONED: if every team and lone wave of that grid should
+        // give up -- ADVICE r4 --, the blocks nobody took read 0xfffffffe, not what the caller's buffer held before)
+        out_len[b] = 0xfffffffeu;
         return;
+    }
     const uint32_t n = block_length(in_len, total_len, in_stride, b);
     if (n > kMaxBlock) {  // caller error: flagged, nothing written
         out_len[b] = 0xffffffffu;  // (every lane, same address, same value: see the note at the dual kernel)
@@ -2332,6 +2364,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (c != 0) {
             if (lane == 0)
                 queue[(c == 2 ? 0u : queue_half) + atomicAdd(&select[4 + c], 1u)] = b;
+            out_len[b] = 0xfffffffeu;  // (poisoned until the team kernel has compressed it: see above)
             return;
         }
         __builtin_amdgcn_wave_barrier();
@@ -2626,6 +2659,7 @@ void set_profile_events(hipEvent_t single0, hipEvent_t single1, hipEvent_t multi
 {
     tl_profile = ProfileEvents{single0, single1, multi0, multi1};
 }
+void drop_profile_events() { tl_profile = ProfileEvents{}; }
 
 static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32_t *d_in_len, uint64_t total_len,
                              uint32_t n_blocks, void *d_dst, uint64_t dst_stride, uint32_t *d_out_len,
@@ -2641,8 +2675,12 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
         uint32_t T = 256;
         while (T < 16384 && T < in_stride)
             T <<= 1;
+        if (prof.single0)  // (the one kernel of such a launch: the "one wavefront per block" pair)
+            (void)hipEventRecord(prof.single0, stream);
         hipLaunchKernelGGL(compress_small_blocks_kernel, dim3(n_blocks), dim3(64), 2 * T, stream, src,
                            (uint32_t)in_stride, n_blocks, dst, dst_stride, d_out_len, flags);
+        if (prof.single1)
+            (void)hipEventRecord(prof.single1, stream);
         return hipGetLastError();
     }
     const bool dual_ok = dual && dual->tables && n_blocks >= dual->min_blocks;

@@ -44,6 +44,10 @@ hipError_t launch_compress_blocks(const void *d_src, uint64_t in_stride, const u
 // right around the persistent kernel's (team or multi-wave), on the launch's stream; null events are skipped.
 // One shot: cleared by the launch that used it.
 void set_profile_events(hipEvent_t single0, hipEvent_t single1, hipEvent_t multi0, hipEvent_t multi1);
+// Disarms the hook: called when sz_compress_blocks_hip / sz_compress_stream_hip return, on EVERY path (argument
+// errors, the accelerator-format kernel, which records nothing), so that events handed over for one call are never
+// recorded by a later, unrelated one -- possibly after their owner has destroyed them.
+void drop_profile_events();
 
 // SZ_FLAG_HW_COMPAT (snappy_hwcompat.hip): the element stream of the reference accelerator's own datapath, one wave per job
 constexpr uint32_t kFlagHwCompat = 2u;  // == SZ_FLAG_HW_COMPAT

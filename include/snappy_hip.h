@@ -111,7 +111,12 @@ SZ_API size_t sz_max_compressed_length(size_t n);
  * Block b reads d_src + b*in_stride, d_in_len[b] bytes (d_in_len == NULL: in_stride bytes each;
  * every length must be <= 65536), and writes d_dst + b*dst_stride and d_out_len[b].
  * dst_stride must be >= sz_max_compressed_length(longest block) + 5.
- * One 64-lane wavefront per block, hash table in LDS. */
+ * One 64-lane wavefront per block, hash table in LDS.
+ * d_out_len[b] is the compressed size, or a marker: 0xffffffff = the block was longer than 64 KiB (nothing written),
+ * 0xfffffffe = the block was NOT compressed (a wave of the persistent kernel gave up after seconds without its team
+ * mate -- a fault, never seen in 6 M soak blocks; the call still returns SZ_OK because it is asynchronous).  A block
+ * that a sampled launch hands to the persistent kernel is marked 0xfffffffe before that kernel starts, so a block
+ * nobody got to reads as not compressed, never as stale data.  sz_stream_offsets / sz_pack_stream_hip refuse markers. */
 SZ_API int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *d_in_len,
                            uint32_t n_blocks, void *d_dst, size_t dst_stride,
                            uint32_t *d_out_len, uint32_t flags, void *stream);
@@ -121,7 +126,9 @@ SZ_API int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uin
  * around the launch of the kernel that can be the launch's dominant one -- single_start / single_stop around the
  * one-wavefront-per-block kernel, multi_start / multi_stop around the persistent kernel for compressible launches
  * (both are enqueued when a data sample chooses between them; the one not chosen exits at once).  NULL handles are
- * skipped; one shot.  Events are created and read by the caller (hipEventCreate, hipEventElapsedTime). */
+ * skipped; one shot: the call that follows disarms the hook on every path (an argument error or SZ_FLAG_HW_COMPAT
+ * records nothing and disarms it all the same; a launch of fixed blocks of <= 8 KiB has one kernel, recorded by the
+ * single_* pair).  Events are created and read by the caller (hipEventCreate, hipEventElapsedTime). */
 SZ_API int sz_profile_next_launch(void *single_start, void *single_stop, void *multi_start, void *multi_stop);
 
 /* Same kernel for ONE contiguous input of n bytes (n < 2^32) cut into consecutive 64 KiB fragments

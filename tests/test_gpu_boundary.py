@@ -56,6 +56,80 @@ def test_host_compress_is_snappy_compress(mode, monkeypatch):
     assert P.uncompress(whole) == mtg
 
 
+
+def test_host_api_one_fragment_size_sweep():
+    """a single fragment goes through the small-block kernel (n <= 8 192, one block of in_stride = n) or the
+    single kernel (larger; the slot is sized to its bound and the length / status words lie right behind it): every
+    size class, the 8192/8193 switch, sizes that are no multiple of 16, text and noise, each against the oracle with a
+    round trip through sz_uncompress; and a damaged one-fragment stream is refused."""
+    P = pkg()
+    mtg, noise = fuzzgen.corpus("mtg"), fuzzgen.corpus("random_ascii")
+    for n in (15, 16, 63, 64, 130, 511, 512, 4096, 8191, 8192, 8193, 16384, 65535):
+        for data in (mtg[1000:1000 + n], noise[7:7 + n]):
+            got = P.compress(data)
+            assert got == oracle_lib.raw_compress(data), (n, data[:8])
+            assert P.uncompress(got) == data, n
+            if n >= 63:
+                bad = bytearray(got)
+                bad[len(bad) // 2] ^= 0x5a  # most flips break an element; every one must be refused or decode to something else, never crash
+                try:
+                    assert P.uncompress(bytes(bad)) != data or bytes(bad) == got
+                except P.SnappyHipError as e:
+                    assert e.code in (P.SZ_ECORRUPT, P.SZ_ENOSPC)
+    with pytest.raises(P.SnappyHipError):
+        P.uncompress(oracle_lib.raw_compress(mtg[:130])[:-3])  # the RoCC driver's size, truncated
+
+
+def test_profile_hook_is_one_shot_on_every_path():
+    """events handed to sz_profile_next_launch belong to the NEXT compress call whatever becomes of it: a
+    call that fails its argument check, or takes the accelerator-format kernel, records nothing and disarms the hook;
+    the call after it must not record into them."""
+    import torch
+    P = pkg()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipEventQuery.argtypes = [ctypes.c_void_p]
+    hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+    ev = []
+    for _ in range(4):
+        e = ctypes.c_void_p()
+        assert hip.hipEventCreate(ctypes.byref(e)) == 0
+        ev.append(e.value)
+    dev = torch.device("cuda:0")
+    nb = 64
+    src = torch.zeros(nb * 65536, dtype=torch.uint8, device=dev)
+    dst = torch.empty(nb * P.SLOT_STRIDE, dtype=torch.uint8, device=dev)
+    ol = torch.zeros(nb, dtype=torch.int32, device=dev)
+    t = ctypes.c_float()
+    # (1) armed, then a call that fails its argument check (stride too small): disarmed, nothing recorded
+    P.profile_next_launch(*ev)
+    rc = P.lib().sz_compress_blocks_hip(ctypes.c_void_p(src.data_ptr()), 65536, None, nb, ctypes.c_void_p(dst.data_ptr()), 100,
+                                        ctypes.c_void_p(ol.data_ptr()), 1, None)
+    assert rc == P.SZ_ENOSPC
+    P.compress_blocks(src, 65536, nb, dst=dst, out_len=ol)  # an unrelated launch: must not touch the events
+    torch.cuda.synchronize()
+    assert hip.hipEventElapsedTime(ctypes.byref(t), ev[0], ev[1]) != 0, "a later, unrelated launch recorded into events of a failed call"
+    hip.hipGetLastError()
+    # (2) armed, then the accelerator-format kernel: disarmed as well
+    P.profile_next_launch(*ev)
+    P.compress_blocks(src, 65536, nb, dst=dst, out_len=ol, hw_compat=True)
+    P.compress_blocks(src, 65536, nb, dst=dst, out_len=ol)
+    torch.cuda.synchronize()
+    assert hip.hipEventElapsedTime(ctypes.byref(t), ev[0], ev[1]) != 0
+    hip.hipGetLastError()
+    # (3) armed, then a real launch: the single kernel's pair is recorded; a launch of small fixed blocks records it too
+    P.profile_next_launch(*ev)
+    P.compress_blocks(src, 65536, nb, dst=dst, out_len=ol)
+    torch.cuda.synchronize()
+    assert hip.hipEventElapsedTime(ctypes.byref(t), ev[0], ev[1]) == 0 and t.value > 0
+    P.profile_next_launch(*ev)
+    P.compress_blocks(src, 4096, nb, dst=dst, out_len=ol)
+    torch.cuda.synchronize()
+    assert hip.hipEventElapsedTime(ctypes.byref(t), ev[0], ev[1]) == 0 and t.value > 0
+    for e in ev:
+        hip.hipEventDestroy(ctypes.c_void_p(e))
+
+
 def test_host_uncompress_rejects_malformed():
     P = pkg()
     good = oracle_lib.raw_compress(b"hello hello hello hello hello hello, said the fox to the socks")
