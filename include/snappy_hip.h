@@ -91,9 +91,11 @@ extern "C" {
                                      36 rows; on repeat-5000 and on every `real` row of 5 000 bytes or more (text whose
                                      tail repeats its head 4 185 bytes back) the hardware reports 8 and 204..1 257 bytes
                                      MORE than this model (tests/test_hw_model.py) -- its pipeline loses or breaks far
-                                     matches in a way that depends on cycle-level timing of modules that are not in the
-                                     reference tree (the scratchpad and its DMA).  Not "the accelerator's format" beyond
-                                     that evidence.  One wavefront per block, 64 positions per step: a compatibility
+                                     matches where the data pointer catches up with the scratchpad's load front
+                                     (MemoryController.scala:81-88, CompressionAccelerator.scala:296-305), which depends on
+                                     cycle-level DMA timing: the scratchpad, its controller and the read aligner ARE in the
+                                     reference tree, icenet's StreamReader/Writer behind them and the test RAM's latency
+                                     are not.  Not "the accelerator's format" beyond that evidence.  One wavefront per block, 64 positions per step: a compatibility
                                      mode, not a fast path. */
 
 /* RoCC command surface constants (tests/compression.c:8-15) */
