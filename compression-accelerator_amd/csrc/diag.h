@@ -31,9 +31,20 @@ static constexpr uint32_t kTraceCap = 16384, kTraceBlocks = 8;
 #ifdef SZ_ABLATION
 #define ABLATION_BREAK_IF(c) if (c) break
 #define ABLATION_KEEPS(c) (c)
+// What is one instruction worth?  64 independent vector instructions (4 groups of 16: no chain of dependences, so what
+// they cost is issue slots, not latency) where bit `bit` of the launch's flags asks for them: 0x1000 in the lone waves'
+// tile loop, 0x2000 off the token's path of a team's turn (behind the element writer), 0x4000 on it (behind the
+// stale check); output unchanged (tools/padbench.py, EXPERIMENTS.md R5.4).
+#define ABLATION_PAD(flags, bit) do { if ((flags) & (bit)) { uint32_t p0_ = lane, p1_ = lane, p2_ = lane, p3_ = lane; _Pragma("unroll") for (int q_ = 0; q_ < 16; q_++) { \
+    asm volatile("v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4" : "+v"(p0_), "+v"(p1_), "+v"(p2_), "+v"(p3_) : "v"(lane)); } } } while (0)
+// ... and scalar ones (the scalar port: one per ~4 clocks per SIMD whatever the number of waves): 0x10000 / 0x20000 / 0x40000
+#define ABLATION_PAD_S(flags, bit) do { if ((flags) & (bit)) { uint32_t p0_ = (flags), p1_ = (flags), p2_ = (flags), p3_ = (flags); _Pragma("unroll") for (int q_ = 0; q_ < 16; q_++) { \
+    asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1\n\ts_add_u32 %3, %3, 1" : "+s"(p0_), "+s"(p1_), "+s"(p2_), "+s"(p3_) :: "scc"); } } } while (0)
 #else
 #define ABLATION_BREAK_IF(c) do { } while (0)
 #define ABLATION_KEEPS(c) true
+#define ABLATION_PAD(flags, bit) do { } while (0)
+#define ABLATION_PAD_S(flags, bit) do { } while (0)
 #endif
 
 #ifdef SZ_EXP_COUNT

@@ -379,7 +379,7 @@ int sz_compress_blocks_hip(const void *d_src, size_t in_stride, const uint32_t *
     }
 #ifdef SZ_ABLATION  // diagnostic builds only: timing ablations that produce wrong output
     if (const char *dbg = getenv("SZ_DEBUG_FLAGS"))
-        flags |= (uint32_t)strtoul(dbg, nullptr, 0) & 0xff00u;
+        flags |= (uint32_t)strtoul(dbg, nullptr, 0) & 0x7ff00u;
 #endif
     szk::DualScratch view;
     std::shared_ptr<DualSlot> slot = dual_slot_for(static_cast<hipStream_t>(stream), n_blocks, in_stride, d_in_len, &view);

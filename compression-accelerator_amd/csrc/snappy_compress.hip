@@ -44,11 +44,8 @@ namespace szk {
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxTable = 16384u;
 static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
-#ifndef SZ_NT_GATHER
-#define SZ_NT_GATHER 0
-#endif
 #ifndef SZ_SPEC_MODE
-#define SZ_SPEC_MODE 0  // head of the next tile issued ahead of the walk: 0 never (measured best), 1 waves with the table in LDS, 2 all
+#define SZ_SPEC_MODE 0  // head of the next tile issued ahead of the walk: 0 never (measured best), 1 waves with the table in LDS, 2 all, 3 waves with the table in global memory with the staleness worked out in registers (round 5: -15 %)
 #endif
 static constexpr uint32_t kFastMargin = 128u;  // the fast dense path stays this far from the last probe position
 
@@ -988,6 +985,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         uint32_t newc = tab.get(th);
                         uint64_t sel = ballot64(newc != tcand) & ~below63(e2);
                         TRACE(2); MARK("T2");
+                        ABLATION_PAD(flags, 0x4000u);
+                        ABLATION_PAD_S(flags, 0x40000u);
                         uint64_t Vacc = 0, Hpacc = 0;
                         uint64_t Cacc = 0;  // lanes of this tile whose table entry this turn has written
                         uint32_t redo_head = 0;
@@ -1228,6 +1227,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         if (__builtin_expect(has_long != 0, 0))
                             op = emit_copy(out, op, Lip - Lcnd, Lm, lane);
                         TRACE(8); MARK("T8");
+                        ABLATION_PAD(flags, 0x2000u);
+                        ABLATION_PAD_S(flags, 0x20000u);
                         if (!cont) {  // this wave goes on alone (general code below, or the end of the block)
                             poisoned = poisoned || tpois != 0;
                             P = P2;
@@ -1271,7 +1272,12 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 // arrived.  States this path does not take (a scan that may reach probe 32, the last ~128
                 // bytes of the block) go back to the general code with (P, chain, sc, next_emit) as they
                 // stand.  tests/tile_model.py states the same algebra in plain integers (checked on the CPU).
-                constexpr bool kSpec = SZ_SPEC_MODE == 2 || (SZ_SPEC_MODE == 1 && Tab::kInLds);
+                // (SZ_SPEC_MODE 3, round 5: the waves whose table is in GLOBAL memory only, and what tile t has written
+                // since the look-ups of tile t+1 is worked out in registers -- the inserted lanes' hashes against the new
+                // tile's -- instead of by a second look-up: a wave with its table in memory spends most of a tile waiting
+                // for two dependent round trips, look-up then candidate strings, and both now travel under the tile before)
+                constexpr bool kSpec = SZ_SPEC_MODE == 2 || (SZ_SPEC_MODE == 1 && Tab::kInLds) || (SZ_SPEC_MODE == 3 && !Tab::kInLds);
+                constexpr bool kSpecInReg = SZ_SPEC_MODE == 3 && !Tab::kInLds;
                 first_scan = false;
                 // current tile: first dword of each position, hash, candidate (as validated), match
                 // length for the walk (4..31, or 64: reaches 32 bytes and goes on), lanes whose candidate matches
@@ -1285,6 +1291,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 bool have_spec = false;
                 // visits of the current tile accumulated for the element writer
                 uint64_t Vacc = 0, Hpacc = 0;
+                uint64_t Cacc = 0;  // (kSpecInReg) lanes of the current tile that have been inserted
                 bool acc_open = false;
                 uint32_t acc_emit = next_emit;
                 uint32_t carry = 0;  // lane j: byte acc_emit + j of an open literal that began in the tile before
@@ -1312,27 +1319,21 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     tn = tt;
                 };
                 auto head_loads = [&]() {
-#if SZ_NT_GATHER
-                    if (!Tab::kInLds) {
-                        nc = ld128_nt(in + ncand);
-                        nc2 = ld128_nt(in + ncand + 16);
-                    } else
-#endif
-                    {
+                    // (plain loads: the same two as non-temporal loads for the global-table waves -- so that their candidates
+                    // would not push the teams' blocks out of the L2 -- cost 11 % of the text rate, EXPERIMENTS.md R5.3)
                     nc = ld128(in + ncand);  // ncand < pos, pos + 32 <= n here
                     nc2 = ld128(in + ncand + 16);
-                    }
                 };
                 // candidates changed for the lanes in `sel` (their bucket was written after their lookup):
                 // both strings again, hit bit and match length merged in
-                auto patch = [&](uint64_t sel, uint32_t cnow) {
+                auto patch = [&](uint64_t sel, uint32_t cnow, bool own_in_regs = false) {
                     const bool on = __builtin_amdgcn_inverse_ballot_w64(sel);
                     const uint32_t pos = (t << 6) + lane;
                     bool hit = false;
                     if (on) {  // (everything inside: nothing to initialise for the other lanes)
                         tcand = cnow;
                         u32x4 x = na, x2 = na2;  // the lanes' own bytes: still those of the head unless a next head was issued
-                        if (kSpec) {
+                        if (kSpec && !own_in_regs) {
                             x = ld128(in + pos);
                             x2 = ld128(in + pos + 16);
                         }
@@ -1398,6 +1399,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 for (;;) {  // ================================================ one tile per trip
                     // ---- (A) the elements closed inside the tile that is being left (all its visits)
                     MARK("flush");
+                    ABLATION_PAD(flags, 0x1000u);
+                    ABLATION_PAD_S(flags, 0x10000u);
                     if (__builtin_expect(Hpacc != 0, 1)) {
                         const uint32_t jfirst = ctz64(Hpacc);
                         const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(Hpacc);
@@ -1476,7 +1479,20 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     uint32_t cnow = 0;
                     if (kSpec && have_spec && t2 == tn) {
                         // the head issued ahead is this tile: check its lookups against the table
-                        cnow = tab.get(nh);
+                        if constexpr (kSpecInReg) {
+                            // ... as it must stand now: a lane whose bucket one of the lanes inserted since (Cacc: tile t's)
+                            // has written sees the LAST of them (ascending: a later lane of a bucket overrides an earlier)
+                            cnow = ncand;
+                            uint64_t m = Cacc;
+                            while (m) {
+                                const uint32_t j = ctz64(m);
+                                m &= m - 1;
+                                const uint32_t hv = lane_get(th, j);
+                                cnow = nh == hv ? (t << 6) + j : cnow;
+                            }
+                        } else {
+                            cnow = tab.get(nh);
+                        }
                         stale = ballot64(cnow != ncand);
                         if (chain2 && !pm1_done) {  // P-1 goes in first: the lanes of its bucket then see it
                             // (P-1 is lane e2-1 of the new tile, or -- a copy that ended with the old tile
@@ -1507,10 +1523,11 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     }
                     PROF_LAPV(22);
                     if (stale)
-                        patch(stale, cnow);
+                        patch(stale, cnow, true);
                     PROF_LAPV(24);
                     Vacc = 0;
                     Hpacc = 0;
+                    Cacc = 0;
                     acc_open = chain2 == 0;
                     acc_emit = next_emit;
                     e = e2;
@@ -1663,6 +1680,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         next_emit = emit2;
                         Vacc |= V;
                         Hpacc |= Hp;
+                        if (kSpecInReg)
+                            Cacc |= C;
                         long_lane = ll;  // (64: none)
                         // (one way out of the visits of a tile: every exit of its own costs a set of copies)
                         if (__builtin_expect(poisoned | (ll < 64) | ((P2 >> 6) != t), 1))
@@ -1672,6 +1691,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         const uint32_t e2s = P2 & 63u;
                         if (chain2 && lane == e2s - 1)
                             tab.put(th, pos);
+                        if (kSpecInReg && chain2)
+                            Cacc |= 1ull << ((e2s - 1u) & 63u);
                         asm volatile("" ::: "memory");
                         const uint32_t cn = tab.get(th);
                         const uint64_t st = ballot64(cn != tcand) & ~below63(e2s);
