@@ -430,13 +430,13 @@ static constexpr uint32_t kTeamLost = 0xfffffffbu;    // return value of a wave 
 #define SZ_TEAM_SPIN_CAP (1u << 24)  // polls before a waiting wave gives the block up (seconds: only a lost wave gets there)
 #endif
 #ifndef SZ_TEAM_BASE_PRIO
-#define SZ_TEAM_BASE_PRIO 1  // issue priority of a team's waves off the token's path (the lone waves of a workgroup have 0)
+#define SZ_TEAM_BASE_PRIO 2  // issue priority of a team's waves off the token's path (the lone waves of a workgroup have 0; round 5: 2 / 3 against 1 / 2: low-entropy +2.7 %, text and mix +0.4 %)
 #endif
 #ifndef SZ_TEAM_POLL_SLEEP
 #define SZ_TEAM_POLL_SLEEP 3  // s_sleep units (64 clocks) between two polls of a token
 #endif
 #ifndef SZ_TEAM_PRIO
-#define SZ_TEAM_PRIO 2  // issue priority of the wave that holds the parse token
+#define SZ_TEAM_PRIO 3  // issue priority of the wave that holds the parse token
 #endif
 #ifndef SZ_TEAM_POLL_BACKOFF_MULT
 #define SZ_TEAM_POLL_BACKOFF_MULT 4
@@ -2050,28 +2050,56 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
             }
             const uint32_t v = a.x;
             uint32_t h = 0, cand = 0, w = p & 0xffffu;
-            if (valid) {
-                h = (v * kHashMul) >> shift;
-                cand = tab.get(h);
-                tab.put(h, p);
-                asm volatile("" ::: "memory");  // the read-back below must come from LDS, not from p
-                w = tab.get(h);
-            }
             const uint32_t nvalid = (uint32_t)__builtin_popcountll(__ballot(valid));  // valid is a prefix
-            const uint64_t losers = __ballot(valid && w != (p & 0xffffu));
             uint32_t cut = 64;
-            if (losers) {
-                // Two lanes of this batch share a bucket: serial order says the later one must see the
-                // earlier one's position.  Roll everything back, keep the longest collision-free prefix.
+            if constexpr (Tab::kInLds) {
+                if (valid) {
+                    h = (v * kHashMul) >> shift;
+                    cand = tab.get(h);
+                    tab.put(h, p);
+                    asm volatile("" ::: "memory");  // the read-back below must come from LDS, not from p
+                    w = tab.get(h);
+                }
+                const uint64_t losers = __ballot(valid && w != (p & 0xffffu));
+                if (losers) {
+                    // Two lanes of this batch share a bucket: serial order says the later one must see the
+                    // earlier one's position.  Roll everything back, keep the longest collision-free prefix.
+                    if (valid)
+                        tab.put(h, cand);
+                    uint64_t L = losers;
+                    while (L) {
+                        const uint32_t hv = lane_get(h, ctz64(L));
+                        const uint64_t G = __ballot(valid && h == hv);
+                        L &= ~G;
+                        const uint64_t G2 = G & (G - 1);
+                        const uint32_t second = ctz64(G2);
+                        cut = second < cut ? second : cut;
+                    }
+                    if (valid && lane < cut)
+                        tab.put(h, p);
+                    UNIFORM_JOIN();
+                }
+            } else {
+                // Table in global memory: a read-back would be one more round trip to the L2 in every batch (round 5:
+                // a batch had four dependent ones -- probe bytes, look-up, read-back, candidate strings).  Lanes of
+                // one bucket are found in the LDS scratch bitmap, as in the dense paths, BEFORE anything is written:
+                // nothing to roll back, the lanes below the second user of a bucket are inserted.
+                uint32_t old = 0;
+                const uint32_t bit = 1u << (((v * kHashMul) >> shift) & 31u);
+                if (valid) {
+                    h = (v * kHashMul) >> shift;
+                    cand = tab.get(h);
+                    old = __hip_atomic_fetch_or(tab.bm_word(h), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                uint64_t L = __ballot(valid && (old & bit) != 0);
                 if (valid)
-                    tab.put(h, cand);
-                uint64_t L = losers;
+                    __hip_atomic_store(tab.bm_word(h), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 while (L) {
                     const uint32_t hv = lane_get(h, ctz64(L));
                     const uint64_t G = __ballot(valid && h == hv);
                     L &= ~G;
                     const uint64_t G2 = G & (G - 1);
-                    const uint32_t second = ctz64(G2);
+                    const uint32_t second = G2 ? ctz64(G2) : 64u;  // (a lane alone in G shared its BIT with another bucket)
                     cut = second < cut ? second : cut;
                 }
                 if (valid && lane < cut)
