@@ -40,7 +40,12 @@ for w, (kern, nb, cmd) in W.items():
     wr = c.get("WRITE_SIZE", 0) * 1024 + sum(med[k].get("WRITE_SIZE", 0) * 1024 for k in other)
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         res.update({"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_traffic_bytes_per_launch": rd + wr,
-                    "hbm_traffic_includes_kernels": [kern] + other})
+                    "hbm_traffic_includes_kernels": [kern] + other,
+                    "fetch_bytes_raw_per_launch": rd / 2,
+                    "traffic_note": "the guide's rule (FETCH_SIZE x 2: exact for wide coalesced streaming reads on gfx950).  For the compressible "
+                                    "workloads the reads are 64-byte gathers (candidate strings, table look-ups) that the x 2 over-counts -- the raw "
+                                    "figure is fetch_bytes_raw_per_launch -- and FETCH_SIZE counts what the L2 fetches over the fabric, Infinity Cache "
+                                    "hits included, not only HBM"})
     if c.get("SQ_LDS_IDX_ACTIVE"):
         res["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]
     if "SQ_WAVE_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
