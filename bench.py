@@ -642,6 +642,8 @@ def rank_main(args):
                          "kernel": main_res["kernel_name"] or "szk::compress_blocks_kernel", "kernel_ms_avg": round(k_ms, 4),
                          "kernel_ms_how": "HIP events recorded by the library right around this kernel's launch on the launch's stream (sz_profile_next_launch), mean over every %dth timed step" % EVENT_EVERY,
                          "call_ms_avg": round(float(np.mean(main_res["call_ms"])), 4),
+                         "call_ms_what": "the whole call on the steps that carry events (three timed pairs: ~6 us each); what the call costs beside its dominant kernel without them: side_kernels_us",
+                         "side_kernels_us": round((main_res["elapsed_s"] / K * 1e3 - k_ms) * 1e3, 1),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "peak_source": "MI355X HBM3E spec (MI355X_MICROARCH.md); device reports %s, %d CUs"
                                         % (props.name, props.multi_processor_count)},
