@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/soak.py -- long differential run of the GPU compressor against the oracle (GPU box).
-usage: soak.py [n_cases] [seed]   -- every case through the single, the team and the multi-wave kernel."""
+usage: soak.py [n_cases] [seed]   -- every case through the default choice (batches of 2 500 mixed blocks: sampled, and routed
+block by block since round 5), the single, the team and the multi-wave kernel."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,7 +14,7 @@ rs = np.random.RandomState(seed0)
 edges = [0, 1, 14, 15, 16, 17, 31, 32, 33, 47, 48, 63, 64, 65, 79, 80, 81, 95, 96, 97, 255, 256, 257, 4095, 4096, 4097,
          16383, 16384, 16385, 32767, 32768, 65519, 65520, 65521, 65535, 65536]
 bad = 0; done = 0; t0 = time.time()
-BATCH = 1500
+BATCH = 2500
 while done < n_cases:
     cases = []
     for i in range(min(BATCH, n_cases - done)):
@@ -23,8 +24,11 @@ while done < n_cases:
         cases.append((kind, seed0 + done + i, n))
     blocks = [fuzzgen.gen(k, s, n).tobytes() for k, s, n in cases]
     want = [oracle_lib.raw_compress(b) for b in blocks]
-    for mode in ("single", "team", "dual"):
-        os.environ["SZ_KERNEL"] = mode
+    for mode in ("auto", "single", "team", "dual"):
+        if mode == "auto":
+            os.environ.pop("SZ_KERNEL", None)
+        else:
+            os.environ["SZ_KERNEL"] = mode
         got = compress_many(blocks)
         for c, g, w in zip(cases, got, want):
             if g != w:
@@ -48,5 +52,5 @@ while done < n_cases:
             print("DECOMPRESS MISMATCH", cases[i], int(stt[i]), int(ul[i]), flush=True)
     done += len(cases)
     print("%d cases, %d mismatches, %.0f s" % (done, bad, time.time() - t0), flush=True)
-print("soak done: %d cases x 3 kernels, %d mismatches" % (done, bad))
+print("soak done: %d cases x 4 modes, %d mismatches" % (done, bad))
 sys.exit(1 if bad else 0)
