@@ -241,6 +241,42 @@ __device__ __forceinline__ uint32_t match_length(const uint8_t *__restrict__ in,
             d |= (a[k].x ^ b[k].x) | (a[k].y ^ b[k].y) | (a[k].z ^ b[k].z) | (a[k].w ^ b[k].w);
         return ballot64(d != 0) != 0;
     };
+    // (round 5) A match whose offset IS the step -- data that repeats with a period of kPieces KiB: pages, records, the
+    // low-entropy workload's 4 KiB pattern -- compares every step's bytes with the step before: the candidate string of a
+    // step is what the step before loaded as ITS string, so only one of the two strings is read from memory (half the
+    // loads of the one phase of such a block that is bound by bandwidth: every wave of the launch is in it at once).
+    // A loop of its own: two sets of registers live at a time (this step's bytes and the last step's), as in the general one.
+    if (ip - cand == 1024u * kPieces && ip + m + 2048 * kPieces <= n) {
+        u32x4 pb[kPieces];
+        {
+            u32x4 a[kPieces];
+#pragma unroll
+            for (int k = 0; k < kPieces; k++) {
+                a[k] = ld128(in + cand + m + 1024 * k + 16 * lane);
+                pb[k] = ld128(in + ip + m + 1024 * k + 16 * lane);
+            }
+            if (differ(a, pb)) {
+                ML_LAP(2);
+                return locate(a, pb);
+            }
+            m += 1024 * kPieces;
+        }
+        while (ip + m + 1024 * kPieces <= n) {
+            u32x4 b[kPieces];
+#pragma unroll
+            for (int k = 0; k < kPieces; k++)
+                b[k] = ld128(in + ip + m + 1024 * k + 16 * lane);
+            if (differ(pb, b)) {
+                ML_LAP(2);
+                return locate(pb, b);
+            }
+            ML_LAP(1);
+#pragma unroll
+            for (int k = 0; k < kPieces; k++)
+                pb[k] = b[k];
+            m += 1024 * kPieces;
+        }
+    }
     while (ip + m + 1024 * kPieces <= n) {
         u32x4 a[kPieces], b[kPieces];
 #pragma unroll
