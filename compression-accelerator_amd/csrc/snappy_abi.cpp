@@ -90,7 +90,10 @@ std::shared_ptr<DualSlot> dual_slot_for(hipStream_t stream, uint32_t n_blocks, s
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             return nullptr;
         const uint32_t n_slots = 4u * (uint32_t)cus;  // four workgroups per CU, kGroupWaves waves each
-        const uint32_t min_blocks = (mode == 2 || mode == 4) ? 2u : 2u * n_slots;
+        // (sampled launches from n_slots + 1 blocks up: with at most one block per SIMD the single kernel is as fast on any
+        // data -- one wave alone on its SIMD --, from the second round on the persistent kernel wins on compressible data:
+        // 1 536 text blocks 3.45 -> 2.63 ms, round 5; rounds 1-4: from 2 x n_slots)
+        const uint32_t min_blocks = (mode == 2 || mode == 4) ? 2u : n_slots + 1u;
         if (n_blocks < min_blocks)
             return nullptr;  // (a 130-byte sz_compress never pays for the 64 MiB workspace)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -126,7 +129,7 @@ std::shared_ptr<DualSlot> dual_slot_for(hipStream_t stream, uint32_t n_blocks, s
     // compressible launches: the team kernel (a two-wave team on the LDS table + two global-table waves per
     // workgroup), unless the multi-wave kernel is asked for by name (SZ_KERNEL=dual)
     view->kernel = mode == 2 ? szk::kKernelMulti : szk::kKernelTeam;
-    view->min_blocks = (mode == 2 || mode == 4) ? 2u : 2u * s->sc.n_slots;
+    view->min_blocks = (mode == 2 || mode == 4) ? 2u : s->sc.n_slots + 1u;
     if (n_blocks < view->min_blocks)
         return nullptr;
     return s;

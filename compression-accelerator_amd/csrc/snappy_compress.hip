@@ -2331,7 +2331,7 @@ __device__ __forceinline__ bool launch_is_mixed(const uint32_t *__restrict__ sel
 // totals with plain stores and clears the words the kernels behind it count in.
 __global__ __launch_bounds__(256) void sample_compressibility_kernel(
     const uint8_t *__restrict__ src, uint64_t in_stride, const uint32_t *__restrict__ in_len,
-    uint64_t total_len, uint32_t n_blocks, uint32_t *__restrict__ select)
+    uint64_t total_len, uint32_t n_blocks, uint32_t *__restrict__ select, uint32_t small_launch)
 {
     __shared__ uint32_t bitmap[2048];  // 65536 bits
     __shared__ uint32_t class_bm[384];
@@ -2390,8 +2390,17 @@ __global__ __launch_bounds__(256) void sample_compressibility_kernel(
         d = lane_get(wave_inclusive_sum(d), 63);
         p = lane_get(wave_inclusive_sum(p), 63);
         c = (ballot64((c & 1u) != 0) ? 1u : 0u) | (ballot64((c & 2u) != 0) ? 2u : 0u) | (ballot64((c & 4u) != 0) ? 4u : 0u);
+        // A small launch (fewer than two blocks per SIMD) that mixes classes: the single kernel takes all of it, as in
+        // rounds 1-4 -- with a handful of expensive blocks, the persistent kernel's lone waves would take most of them and
+        // each needs twice a team's time (mix of 1 536 blocks: 1.78 ms by the single kernel, 2.29 ms routed).
+        uint32_t all_kinds = 0;  // select[8]: the single kernel takes every block of the launch, compressible ones too: its instance with the fast dense path
+        if (small_launch && __builtin_popcount(c & 7u) >= 2) {
+            d = 0;
+            c = 1;
+            all_kinds = 1;
+        }
         if (t < 16)
-            select[t] = t == 0 ? d : t == 1 ? p : t == 7 ? c : 0u;  // (select[15]: the arrival counter, zero again)
+            select[t] = t == 0 ? d : t == 1 ? p : t == 7 ? c : t == 8 ? all_kinds : 0u;  // (select[15]: the arrival counter, zero again)
     }
 }
 
@@ -2456,7 +2465,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     const HashTab<true> tab{lds_tab, nullptr, nullptr, nullptr};
     uint32_t op;
-    if (select)  // auto mode, and the sample (or this block's class) says incompressible: the instance without the fast dense path
+    if (select && select[8] == 0)  // auto mode, and the sample (or this block's class) says incompressible: the instance without the fast dense path
         op = compress_one_block<64, false, HashTab<true>, false>(tab, src + (uint64_t)b * in_stride, n,
                                                                          dst + (uint64_t)b * dst_stride, flags, lane);
     else
@@ -2780,7 +2789,7 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
         // safe: no host sync)
         const uint32_t ns = n_blocks < 64 ? n_blocks : 64;
         hipLaunchKernelGGL(sample_compressibility_kernel, dim3(ns), dim3(256), 0, stream, src, in_stride,
-                           d_in_len, total_len, n_blocks, dual->select);
+                           d_in_len, total_len, n_blocks, dual->select, n_blocks < 2u * dual->n_slots ? 1u : 0u);
     }
     if (!dual_ok || sampled) {
         if (prof.single0)

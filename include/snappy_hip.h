@@ -233,7 +233,7 @@ SZ_API int sz_stream_offsets(const uint32_t *lens, uint64_t n_blocks, uint64_t b
 SZ_API void sz_release_thread_resources(void);
 /* Frees the 64 MiB workspace the compress entry points keep for `stream` on the current device
  * (waits for the stream first).  The workspace is created by the first launch on the stream that
- * has enough blocks for the multi-wave kernel (8 x CUs), never by small calls.  Call this before
+ * has enough blocks for the persistent kernel (more than 4 x CUs: one per SIMD), never by small calls.  Call this before
  * destroying a stream that was used for compression if the process creates many; the next large
  * compress call on the stream allocates a new one.  Host threads may launch on one stream at the
  * same time: the launch sequence of each call is enqueued as a unit. */

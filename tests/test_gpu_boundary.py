@@ -457,7 +457,7 @@ def test_device_api_is_graph_capturable():
     replays on new data in the same buffers."""
     import torch
     P = pkg()
-    nb = 2200  # above the auto threshold (8 x CUs): the captured launch includes the multi-wave kernel
+    nb = 2200  # above the auto threshold (4 x CUs): the captured launch includes the persistent kernel
     st = torch.cuda.Stream()
     src = torch.zeros(nb * 65536, dtype=torch.uint8, device="cuda")
     dst = torch.empty(nb * P.SLOT_STRIDE, dtype=torch.uint8, device="cuda")
