@@ -2393,14 +2393,12 @@ __global__ __launch_bounds__(256) void sample_compressibility_kernel(
         // A small launch (fewer than two blocks per SIMD) that mixes classes: the single kernel takes all of it, as in
         // rounds 1-4 -- with a handful of expensive blocks, the persistent kernel's lone waves would take most of them and
         // each needs twice a team's time (mix of 1 536 blocks: 1.78 ms by the single kernel, 2.29 ms routed).
-        uint32_t all_kinds = 0;  // select[8]: the single kernel takes every block of the launch, compressible ones too: its instance with the fast dense path
         if (small_launch && __builtin_popcount(c & 7u) >= 2) {
             d = 0;
-            c = 1;
-            all_kinds = 1;
+            c = 1u | 8u;  // (bit 3 of select[7]: the single kernel takes every block of the launch, compressible ones too: its instance with the fast dense path)
         }
         if (t < 16)
-            select[t] = t == 0 ? d : t == 1 ? p : t == 7 ? c : t == 8 ? all_kinds : 0u;  // (select[15]: the arrival counter, zero again)
+            select[t] = t == 0 ? d : t == 1 ? p : t == 7 ? c : 0u;  // (select[15]: the arrival counter, zero again)
     }
 }
 
@@ -2437,6 +2435,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (b >= n_blocks)
         return;
     const bool routed = select && launch_is_routed(select, queue_half);
+    // (read here, with the verdict: the same word behind the routed launch's classifier cost a mixed launch 5 % -- mix 156 -> 149 GB/s)
+    const bool lean_instance = select && (select[7] & 8u) == 0;
     if (select && !routed && prefers_dual(select)) {  // auto mode, one kind of block: the sampled data is compressible, the team kernel runs
         // (every block a persistent kernel is to take starts out POISONED: if every team and lone wave of that grid should
         // give up -- ADVICE r4 --, the blocks nobody took read 0xfffffffe, not what the caller's buffer held before)
@@ -2465,7 +2465,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     const HashTab<true> tab{lds_tab, nullptr, nullptr, nullptr};
     uint32_t op;
-    if (select && select[8] == 0)  // auto mode, and the sample (or this block's class) says incompressible: the instance without the fast dense path
+    if (lean_instance)  // auto mode, and the sample (or this block's class) says incompressible: the instance without the fast dense path
         op = compress_one_block<64, false, HashTab<true>, false>(tab, src + (uint64_t)b * in_stride, n,
                                                                          dst + (uint64_t)b * dst_stride, flags, lane);
     else
