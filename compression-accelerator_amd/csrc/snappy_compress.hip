@@ -44,6 +44,9 @@ namespace szk {
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxTable = 16384u;
 static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
+#ifndef SZ_REVISIT_REGS
+#define SZ_REVISIT_REGS 1  // a second visit's new candidates' strings out of the register buffer (0: from memory, rounds 2-4)
+#endif
 #ifndef SZ_SPEC_MODE
 #define SZ_SPEC_MODE 0  // head of the next tile issued ahead of the walk: 0 never (measured best), 1 waves with the table in LDS, 2 all, 3 waves with the table in global memory with the staleness worked out in registers (round 5: -15 %)
 #endif
@@ -1417,6 +1420,30 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     farmask = ballot64(dist >= run32);
                 };
 
+                // the same for candidates that lie in the current tile (a second visit after a cut): both strings out of registers
+                auto patch_regs = [&](uint64_t sel, uint32_t cnow) {
+                    const bool on = __builtin_amdgcn_inverse_ballot_w64(sel);
+                    const uint32_t r = on ? cnow - (kcur << 7) : 0u;  // (every lane takes part in the shuffles)
+                    const uint32_t i0 = (r >> 2) << 2, sh = r & 3u;
+                    uint32_t d[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++)
+                        d[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i0 + 4 * q), (int)wcur);
+                    u32x4 c, c2;
+                    c.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+                    c.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+                    c.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+                    c.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
+                    c2.x = __builtin_amdgcn_alignbyte(d[5], d[4], sh);
+                    c2.y = __builtin_amdgcn_alignbyte(d[6], d[5], sh);
+                    c2.z = __builtin_amdgcn_alignbyte(d[7], d[6], sh);
+                    c2.w = __builtin_amdgcn_alignbyte(d[8], d[7], sh);
+                    const uint32_t ml = matchlen32(na, na2, c, c2);
+                    tcand = on ? cnow : tcand;
+                    tmlw = on ? (ml == 32 ? 64u : ml) : tmlw;
+                    Hraw = (Hraw & ~sel) | (ballot64(c.x == na.x) & sel);
+                };
+
                 PROF_LAP(14);
                 auto enter_head = [&](uint32_t P2v, uint32_t e2v) {  // bytes, hashes, lookups, candidate loads of P2v's tile
                     head(P2v >> 6);
@@ -1733,7 +1760,12 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         const uint32_t cn = tab.get(th);
                         const uint64_t st = ballot64(cn != tcand) & ~below63(e2s);
                         if (st) {
-                            patch(st, cn);
+                            // (what has been written since the tile's look-ups was written by this tile's own inserts: the new
+                            // candidates lie in the tile, their strings in the register buffer -- no round trip to memory)
+                            if (SZ_REVISIT_REGS && !kSpec)
+                                patch_regs(st, cn);
+                            else
+                                patch(st, cn);
                             jumps();
                         }
                         PROF_LAPV(23);
