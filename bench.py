@@ -277,7 +277,7 @@ def run_workload(P, kind, first_block, n_blocks, steps, warmup, device, dist_on,
         layout = verify_gather(gathered[last], offs[last], out_lens[last], dist.get_rank(), world, n_total, True)
     out_len = out_lens[last]
     sampled = [i for i in range(steps) if i % EVENT_EVERY == 0]
-    call_ms = [ev[i][0].elapsed_time(ev[i][1]) for i in sampled]  # the whole call: reset + sample + compress kernels + ordering kernels
+    call_ms = [ev[i][0].elapsed_time(ev[i][1]) for i in sampled]  # the whole call: sample + both compress kernels (one of them exits at once unless the launch is mixed)
     # the dominant kernel alone (HIP events recorded by the library around its launch, on the launch's stream)
     single_ms = [hev.ms(i, False) for i in sampled]
     multi_ms = [hev.ms(i, True) for i in sampled]
