@@ -32,7 +32,8 @@
  * block queue); it is allocated by the first call on a stream that has enough blocks and is not being
  * captured (a call made during graph capture before that simply uses the one-wave kernel), so make
  * one warm-up call before capturing a graph; sz_release_stream_resources() frees it.  Which kernel
- * runs is chosen per launch from a sample of the data (same output bytes whichever runs).
+ * runs is chosen per launch from a sample of the data -- per BLOCK when the sample meets more than one kind of data: the
+ * one-wave kernel keeps the incompressible blocks, the persistent kernel takes the others -- (same output bytes whichever runs).
  *
  * Environment (all optional, read per call):
  *   SZ_KERNEL  forces a compress kernel: `single` (one wave per block, table in LDS: what incompressible
@@ -40,7 +41,8 @@
  *              with tables in global memory: what compressible launches get), `dual` (rounds 1-2's kernel
  *              for compressible launches: three independent waves per workgroup; kept as a second
  *              implementation for differential tests and A/B).
- *              Unset: the sampled choice between `single` and `team`.
+ *              Unset: the sampled choice between `single` and `team` (launches of more than one block per SIMD; smaller
+ *              ones: `single`).
  *   SZ_DECODE_KERNEL  forces a decode kernel: `single` (one wave per stream), `pair` (two:
  *              one parses the next window while the other moves this one's bytes).  Unset: `pair` for launches
  *              of up to 4 096 streams, `single` above.  Same output either way.
