@@ -453,8 +453,9 @@ def test_all_mtg_cards_48_blocks_bit_exact():
 
 def test_device_api_is_graph_capturable():
     """After one warm-up call on the stream (which creates the workspace), a compress launch -- the
-    counter memset, the sampling kernel and both compress kernels -- records into a hipGraph and
-    replays on new data in the same buffers."""
+    sampling kernel and both compress kernels -- records into a hipGraph and replays on new data in the
+    same buffers, whatever kind of data the replay finds there: incompressible (the single kernel works),
+    text (the team kernel), a mix (both, block by block)."""
     import torch
     P = pkg()
     nb = 2200  # above the auto threshold (4 x CUs): the captured launch includes the persistent kernel
@@ -479,18 +480,31 @@ def test_device_api_is_graph_capturable():
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=st):
             P.compress_blocks(src, 65536, nb, dst=dst, out_len=out_len, stream=torch.cuda.current_stream())
-    for kind in ("rnd", "text", "rnd"):
-        host = fill(kind)
+    def fill_mixed():
+        # every third block text, the others incompressible: the replayed launch is ROUTED block by block (round 5:
+        # the launch state, the queue's counters and the sample's arrival counter reset themselves in every replay)
+        host = np.tile(rnd, nb * 65536 // rnd.size + 2)[7:7 + nb * 65536].copy().reshape(nb, 65536)
+        text = np.tile(mtg, nb * 65536 // mtg.size + 2)[11:11 + nb * 65536].reshape(nb, 65536)
+        host[0::3] = text[0::3]
+        host = host.reshape(-1)
+        src.copy_(torch.from_numpy(host))
+        return host
+
+    for kind in ("rnd", "text", "mixed", "rnd", "mixed", "mixed", "text"):
+        host = fill_mixed() if kind == "mixed" else fill(kind)
         torch.cuda.synchronize()
         out_len.zero_()
         g.replay()
         torch.cuda.synchronize()
         ol = out_len.cpu().numpy()
-        assert (ol > 0).all(), (kind, int((ol > 0).sum()))
-        for b in (0, 1, nb // 2, nb - 1):
+        assert ((ol > 0) & (ol < 80000)).all(), (kind, int((ol > 0).sum()))
+        checked = (0, 1, 2, 3, nb // 2, nb // 2 + 1, nb // 2 + 2, nb - 2, nb - 1) if kind == "mixed" else (0, 1, nb // 2, nb - 1)
+        for b in checked:
             want = oracle_lib.raw_compress(host[b * 65536:(b + 1) * 65536])
             got = dst[b * P.SLOT_STRIDE:b * P.SLOT_STRIDE + int(ol[b])].cpu().numpy().tobytes()
             assert got == want, (kind, b)
+        if kind == "mixed":
+            assert (ol[1::3] == 65542).all() and (ol[0::3] < 40000).all()
 
 
 def test_release_thread_resources_and_reuse():

@@ -121,3 +121,26 @@ def test_a_mixed_launch_costs_about_the_sum_of_its_parts(monkeypatch):
     ratio = t_mixed / (t_c3 + t_text)
     print("mixed %.3f ms, incompressible part %.3f ms, text part %.3f ms: ratio %.2f" % (t_mixed, t_c3, t_text, ratio))
     assert ratio <= 1.35, ratio
+
+
+@pytest.mark.timeout(300, method="thread")
+def test_every_size_around_the_thresholds_of_the_choice(monkeypatch):
+    """The default choice changes hands at one block per SIMD (1 024 on MI355X: below, the single kernel; above, a
+    sample decides) and at two (2 048: from there a mixed launch is routed block by block; below, a mixed launch
+    stays the single kernel's, all kinds).  Mixed, text-only and incompressible launches on both sides of both, every
+    block against the oracle."""
+    import torch
+    from gpu_util import pkg
+    monkeypatch.delenv("SZ_KERNEL", raising=False)
+    P = pkg()
+    dev = torch.device("cuda:0")
+    sys.path.insert(0, build_util.ROOT)
+    import bench
+    for nb in (1023, 1024, 1025, 1536, 2047, 2048, 2049):
+        for kind in ("mix", "text", "c3"):
+            src = bench.make_input(kind, 3, nb, dev)
+            dst = torch.full((nb * P.SLOT_STRIDE,), 0xA5, dtype=torch.uint8, device=dev)
+            ol = torch.zeros(nb, dtype=torch.int32, device=dev)
+            P.compress_blocks(src, 65536, nb, dst=dst, out_len=ol)
+            torch.cuda.synchronize()
+            parity_util.assert_all_blocks_match_oracle(src, dst, ol, nb, P.SLOT_STRIDE, what="%s, %d blocks" % (kind, nb))
