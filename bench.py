@@ -589,12 +589,24 @@ def rank_main(args):
             if r["layout"] is not None:
                 extras[kind].update(r["layout"])
 
+    # The same workloads at four times the size (N = 1 only, 5 steps; `workloads` above stays the row of record): a
+    # 1 GiB launch of text ends ~1.4 ms after its queue is empty -- whole blocks of 2-4 ms on the last workers --, which is
+    # 9 % of it and 2 % of a 4 GiB one (EXPERIMENTS.md R5.4); every block compared with the oracle as everywhere.
+    large = {}
+    if not args.no_extra and world == 1:
+        for kind, nb in (("text", 65536), ("mix", 65538)):
+            r = run_workload(P, kind, 0, nb, 5, 1, device, False)
+            large[kind] = {"input_GBps": round(r["in_bytes"] * 5 / r["elapsed_s"] / 1e9, 2), "blocks_per_gpu": nb, "steps": 5,
+                           "kernel_ms": round(float(np.mean(r["kernel_ms"])), 3), "kernel": r["kernel_name"],
+                           "blocks_differing_from_oracle": r["blocks_differing_from_oracle"]}
+
     stream_row = hw_row = None
     if not args.no_extra and rank == 0 and world == 1:
         stream_row = one_stream(P, "text", 16384, device)
         hw_row = hw_compat_row(P, "text", 16384, device)  # (two rounds of its 8 192 wave slots)
 
-    bad_all = main_res["blocks_differing_from_oracle"] + sum(v["blocks_differing_from_oracle"] for v in extras.values())
+    bad_all = (main_res["blocks_differing_from_oracle"] + sum(v["blocks_differing_from_oracle"] for v in extras.values())
+               + sum(v["blocks_differing_from_oracle"] for v in large.values()))
     if dist_on:
         t = torch.tensor([bad_all], device=device, dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -648,6 +660,7 @@ def rank_main(args):
                          "peak_source": "MI355X HBM3E spec (MI355X_MICROARCH.md); device reports %s, %d CUs"
                                         % (props.name, props.multi_processor_count)},
             "workloads": extras,
+            "workloads_at_4x_size": large,
             "one_stream": stream_row,
             "hw_compat": hw_row,
         }
