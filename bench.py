@@ -449,32 +449,55 @@ def host_cpu():
             "cgroup_cpu_quota": quota, "threads_used": cores}
 
 
+CPU_BATCHES = 5  # timed batches per thread count: the reported rate is their median, the spread is reported beside it
+
+
+def _timed_batches(time_fn, sample_blocks, threads, budget_s):
+    """CPU_BATCHES timed batches of `reps` passes each of time_fn(threads, reps) -> seconds (one untimed probe pass sizes
+    `reps` so that all batches together take about budget_s).  Returns the per-batch rates in GB/s and reps.  A shared
+    box moves a single batch by several x (round 5's driver line had the image's libsnappy at 1.83 GB/s on one thread,
+    13.2 elsewhere): the median of five batches with min / max beside it says whether a figure can be trusted."""
+    sec1 = max(time_fn(threads, 1), 1e-6)
+    reps = max(1, min(400, int(budget_s / CPU_BATCHES / sec1)))
+    rates = []
+    for _ in range(CPU_BATCHES):
+        sec = time_fn(threads, reps)
+        rates.append(sample_blocks * BLOCK * reps / sec / 1e9)
+    return rates, reps
+
+
+def _spread(rates):
+    r = sorted(rates)
+    return {"median": round(r[len(r) // 2], 3), "min": round(r[0], 3), "max": round(r[-1], 3), "batches": len(r),
+            "noisy": bool(r[-1] > 1.5 * r[0])}
+
+
 def cpu_baseline(kind, sample_blocks, budget_s=10.0):
     """The oracle (kind "port": bit-exact CPU restatement of Snappy 1.1.8) on the host cores, on a
     bounded sample of the same workload: pinned pthreads created once, buffers allocated before the
-    clock starts, one warm-up pass, then >= 20 timed passes (oracle_time_compress_blocks; the
-    reference's own loop is workloads/snappy/overlay/root/compress.cc:26-34)."""
+    clock starts, one warm-up pass, then CPU_BATCHES timed batches per thread count (oracle_time_compress_blocks; the
+    reference's own loop is workloads/snappy/overlay/root/compress.cc:26-34).  `value` = the MEDIAN batch on all
+    granted cores; `spread` carries min / max and `noisy` (max > 1.5 x min: another tenant had the cores)."""
     import oracle_lib
     src = make_input(kind, 0, sample_blocks, "cpu").numpy()
     cores, _ = effective_cores()  # the box's real CPU share
     cores = max(1, min(cores, sample_blocks // 8))  # (every thread gets a few blocks)
     res = {}
     for threads in (1, cores):
-        sec1, _ = oracle_lib.time_compress_blocks(src, BLOCK, sample_blocks, threads, 1)
-        reps = max(20, min(2000, int((budget_s / 2) / max(sec1, 1e-6))))
-        if sec1 * 20 > budget_s:  # a slow sample: keep the run bounded, say so
-            reps = max(3, int(budget_s / 2 / sec1))
-        sec, _ = oracle_lib.time_compress_blocks(src, BLOCK, sample_blocks, threads, reps)
-        res[threads] = (sample_blocks * BLOCK * reps / sec / 1e9, reps)
-    out = {"value": round(res[cores][0], 3), "unit": "GB/s", "cores": cores, "kind": "port",
-           "single_thread_GBps": round(res[1][0], 3), "passes": {"1_thread": res[1][1], "%d_threads" % cores: res[cores][1]},
-           "fewer_than_20_passes": min(res[1][1], res[cores][1]) < 20,
+        rates, reps = _timed_batches(lambda t, r: oracle_lib.time_compress_blocks(src, BLOCK, sample_blocks, t, r)[0],
+                                     sample_blocks, threads, budget_s / 2)
+        res[threads] = (_spread(rates), reps)
+    out = {"value": res[cores][0]["median"], "median": res[cores][0]["median"], "unit": "GB/s", "cores": cores, "kind": "port",
+           "spread": res[cores][0], "noisy": bool(res[cores][0]["noisy"] or res[1][0]["noisy"]),
+           "single_thread_GBps": res[1][0]["median"], "single_thread_spread": res[1][0],
+           "passes_per_batch": {"1_thread": res[1][1], "%d_threads" % cores: res[cores][1]},
            "host": host_cpu(),
            "sample": "%d x 64 KiB blocks of workload %s, oracle/snappy_oracle.c, %d pinned pthreads, preallocated buffers, "
-                     "1 warm-up + timed passes" % (sample_blocks, kind, cores)}
+                     "1 warm-up pass + %d timed batches per thread count (median reported)" % (sample_blocks, kind, cores, CPU_BATCHES)}
     lib = _system_libsnappy()
     if lib is not None:  # informational: the real google/snappy of this image, if there is one (BASELINE.md section 4)
         out["system_libsnappy"] = _time_libsnappy(lib, src, sample_blocks, cores, budget_s / 2)
+        out["noisy"] = bool(out["noisy"] or out["system_libsnappy"]["noisy"])
     return out
 
 
@@ -495,34 +518,39 @@ def _system_libsnappy():
 
 def _time_libsnappy(lib, src, sample_blocks, cores, budget_s):
     """The image's google/snappy (C API) in the SAME harness as the port: pinned pthreads created once,
-    preallocated buffers, one warm-up pass, >= 20 timed passes (oracle_time_external_blocks calls the
-    library's snappy_compress per 64 KiB block)."""
+    preallocated buffers, one warm-up pass, CPU_BATCHES timed batches per thread count, median reported
+    (oracle_time_external_blocks calls the library's snappy_compress per 64 KiB block)."""
     import ctypes
     import oracle_lib
     fn = ctypes.cast(lib.snappy_compress, ctypes.c_void_p).value
     res = {}
     for threads in (1, cores):
-        sec1, _ = oracle_lib.time_external_blocks(fn, src, BLOCK, sample_blocks, threads, 1)
-        reps = max(20, min(2000, int((budget_s / 2) / max(sec1, 1e-6))))
-        if sec1 * 20 > budget_s:
-            reps = max(3, int(budget_s / 2 / sec1))
-        sec, ol = oracle_lib.time_external_blocks(fn, src, BLOCK, sample_blocks, threads, reps)
-        res[threads] = sample_blocks * BLOCK * reps / sec / 1e9
-    return {"library": lib._path, "single_thread_GBps": round(res[1], 3), "threads": cores,
-            "threads_GBps": round(res[cores], 3),
+        rates, _ = _timed_batches(lambda t, r: oracle_lib.time_external_blocks(fn, src, BLOCK, sample_blocks, t, r)[0],
+                                  sample_blocks, threads, budget_s / 2)
+        res[threads] = _spread(rates)
+    return {"library": lib._path, "single_thread_GBps": res[1]["median"], "single_thread_spread": res[1], "threads": cores,
+            "threads_GBps": res[cores]["median"], "threads_spread": res[cores],
+            "noisy": bool(res[1]["noisy"] or res[cores]["noisy"]),
             "note": "the image's libsnappy, snappy_compress per block, same pinned-thread harness as the port; "
                     "its bytes equal the oracle's only if it is 1.1.8"}
 
 
-def load_pmc(kind, n_blocks):
+def load_pmc(kind, n_blocks, library_version=""):
     """The committed summary of the rocprofv3 --pmc passes of this workload at this size (profiles/pmc_<kind>_<blocks>.json,
-    written by profiles/pmc_summary.py from the passes tools/profile_r05.sh runs), or {}."""
+    written by tools/pmc_r6_sum.py -- round 5's files by tools/pmc_r5_sum.py -- from the passes tools/profile_r06.sh
+    runs), or {}.  PMC counters need the profiler, so they are not re-measured in a bench run; the file says which
+    sources the measured library was built from (`library_source_id`, the `src` field of sz_version()) and at which
+    commit it was collected, and `_stale` is true when that is not the library this run loaded."""
     path = os.path.join(ROOT, "profiles", "pmc_%s_%d.json" % (kind, n_blocks))
     if not os.path.exists(path):
         return {}
     with open(path) as f:
         d = json.load(f)
-    d["_source"] = "profiles/%s (rocprofv3 --pmc passes, committed; not re-measured in this run)" % os.path.basename(path)
+    sid = d.get("library_source_id")
+    d["_stale"] = (sid is None) or (("src " + sid) not in library_version)
+    d["_source"] = ("profiles/%s (rocprofv3 --pmc passes, committed; not re-measured in this run; collected at commit %s with the "
+                    "library built from sources %s: %s)" % (os.path.basename(path), d.get("collected_at_commit", "?"), sid or "?",
+                                                            "an OLDER build than the one this run loaded" if d["_stale"] else "the build this run loaded"))
     return d
 
 
@@ -556,6 +584,7 @@ def rank_main(args):
     if "gfx950" not in getattr(props, "gcnArchName", "gfx950") and rank == 0:
         print("note: device %s is not gfx950; the roofline peak below is MI355X's" % props.name, file=sys.stderr)
 
+    lib_version = P.lib().sz_version().decode()  # names the toolchain ("untuned toolchain" if not the tuned one) and the sources (`src <id>`)
     B = args.blocks_per_gpu
     main_res = run_workload(P, args.workload, rank * B, B, args.steps, args.warmup, device, dist_on)
 
@@ -568,7 +597,7 @@ def rank_main(args):
             r = run_workload(P, kind, rank * nb, nb, xsteps, 2, device, dist_on, decompress=True)
             k_ms = float(np.mean(r["kernel_ms"]))
             algo = r["in_bytes"] + r["out_bytes"] + 4 * nb  # algorithmic bytes per launch: input read once + output written once + lengths
-            pmc_w = load_pmc(kind, nb)
+            pmc_w = load_pmc(kind, nb, lib_version)
             extras[kind] = {"input_GBps": round(r["in_bytes"] * world * xsteps / r["elapsed_s"] / 1e9, 2), "steps": xsteps,
                             "kernel_ms": round(k_ms, 3), "kernel": r["kernel_name"], "blocks_per_gpu": nb,
                             "compression_ratio": round(r["in_bytes"] / r["out_bytes"], 4),
@@ -580,7 +609,7 @@ def rank_main(args):
                                          "achieved": round(algo / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                          "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                          "traffic": int(pmc_w["hbm_traffic_bytes_per_launch"]) if pmc_w.get("hbm_traffic_bytes_per_launch") else None,
-                                         "traffic_source": pmc_w.get("_source"),
+                                         "traffic_source": pmc_w.get("_source"), "traffic_stale": pmc_w.get("_stale"),
                                          "lds_bank_conflict_frac": pmc_w.get("lds_bank_conflict_frac"),
                                          "resident_waves_per_simd": pmc_w.get("resident_waves_per_simd")},
                             "blocks_differing_from_oracle": r["blocks_differing_from_oracle"],
@@ -591,7 +620,7 @@ def rank_main(args):
 
     # The same workloads at four times the size (N = 1 only, 5 steps; `workloads` above stays the row of record): a
     # 1 GiB launch of text ends ~1.4 ms after its queue is empty -- whole blocks of 2-4 ms on the last workers --, which is
-    # 9 % of it and 2 % of a 4 GiB one (EXPERIMENTS.md R5.4); every block compared with the oracle as everywhere.
+    # 9 % of it and 2 % of a 4 GiB one (EXPERIMENTS.md R5.4, last item); every block compared with the oracle as everywhere.
     large = {}
     if not args.no_extra and world == 1:
         for kind, nb in (("text", 65536), ("mix", 65538)):
@@ -619,8 +648,7 @@ def rank_main(args):
         k_ms = float(np.mean(main_res["kernel_ms"]))
         algo_bytes = main_res["in_bytes"] + main_res["out_bytes"] + 4 * B  # per launch (this rank)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        pmc = load_pmc(args.workload, B)  # HBM bytes per launch etc. from the committed PMC passes (profiles/pmc_summary.py)
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_%s_%d.json" % (args.workload, B))
+        pmc = load_pmc(args.workload, B, lib_version)  # HBM bytes per launch etc. from the committed PMC passes
         traffic = pmc.get("hbm_traffic_bytes_per_launch")
         roof = copy_roof(main_res["in_bytes"], device) if world == 1 else None
         line = {
@@ -628,6 +656,7 @@ def rank_main(args):
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(main_res["elapsed_s"] / K * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "library": lib_version,
             "config": {"workload": {"c3": "C3 tiled data/randomASCII.txt", "text": "C2-like tiled all-mtg-cards.txt",
                                     "c5": "C5 4 KiB text pattern x16", "mix": "C4 mix c3/text/c5"}[args.workload]
                        + ", %d x 64 KiB blocks per GPU (%.2f GiB/GPU)" % (B, B * BLOCK / 2**30),
@@ -643,7 +672,7 @@ def rank_main(args):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": int(traffic) if traffic else None,
-                         "traffic_source": "profiles/%s (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)" % os.path.basename(pmc_path) if traffic else None,
+                         "traffic_source": pmc.get("_source") if traffic else None, "traffic_stale": pmc.get("_stale") if traffic else None,
                          "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"),
                          "resident_waves_per_simd": pmc.get("resident_waves_per_simd"),
                          "copy_roof_GBps": round(roof["best"], 1) if roof else None,
@@ -671,7 +700,7 @@ def rank_main(args):
             for kind, nb_s, budget in (("text", 256, 6.0), ("c5", 512, 3.0), ("mix", 384, 4.0)):
                 if kind in extras:  # the same oracle on the other reported workloads (bounded)
                     t = cpu_baseline(kind, nb_s, budget_s=budget)
-                    extras[kind]["cpu_baseline"] = {k: t[k] for k in ("value", "unit", "cores", "kind", "single_thread_GBps", "sample")}
+                    extras[kind]["cpu_baseline"] = {k: t[k] for k in ("value", "unit", "cores", "kind", "spread", "noisy", "single_thread_GBps", "sample")}
                     if "system_libsnappy" in t:
                         extras[kind]["cpu_baseline"]["system_libsnappy"] = t["system_libsnappy"]
         real_stdout.write(json.dumps(line) + "\n")

@@ -110,7 +110,7 @@ std::shared_ptr<DualSlot> dual_slot_for(hipStream_t stream, uint32_t n_blocks, s
         if (hipMalloc(&t, tbytes) == hipSuccess && hipMalloc(&g, gbytes) == hipSuccess &&
             hipMalloc(&q, qbytes) == hipSuccess && hipMemsetAsync(t, 0, tbytes, stream) == hipSuccess &&
             hipMemsetAsync(g, 0, gbytes, stream) == hipSuccess) {
-            slot->sc.tables = static_cast<uint16_t *>(t);  // (every wave zeroes its table again before each block)
+            slot->sc.tables = static_cast<uint16_t *>(t);  // (never cleared again: a bitmap in LDS says which buckets a block has written; the memset is hygiene)
             slot->sc.select = static_cast<uint32_t *>(g);
             slot->sc.queue = static_cast<uint32_t *>(q);
             slot->sc.queue_cap = szk::kDualQueueEntries;
@@ -313,17 +313,22 @@ int sz_device_count(void)
 int sz_last_hip_error(void) { return tl_hip_error; }
 
 // (the compiler the kernels were built with is part of the version: their speed -- and once their liveness -- has
-// depended on how one clang merged branches and allocated registers; csrc/Makefile warns when it is not the one the
-// numbers under profiles/ were measured with)
+// depended on how one clang merged branches and allocated registers; csrc/Makefile stamps "untuned toolchain" when it
+// is not the one the numbers under profiles/ were measured with.  `src <id>` is the identity of the sources this
+// library was built from -- csrc/Makefile SOURCE_ID, recomputed by tests/build_util.py source_id() --: the GPU box
+// loads whatever .so was pushed, the GPU suite's first test refuses one that was not built from the tree beside it.)
 #define SZ_STR2(x) #x
 #define SZ_STR(x) SZ_STR2(x)
+#ifndef SZ_TOOLCHAIN
+#define SZ_TOOLCHAIN "HIP unknown, untuned toolchain"
+#endif
+#ifndef SZ_SOURCE_ID
+#define SZ_SOURCE_ID "unknown"
+#endif
 const char *sz_version(void)
 {
-    return "snappy_hip 0.4 (gfx950; Snappy 1.1.8 bit-exact; built with clang " SZ_STR(__clang_major__) "." SZ_STR(__clang_minor__) "." SZ_STR(__clang_patchlevel__)
-#ifdef SZ_TOOLCHAIN
-           ", " SZ_TOOLCHAIN
-#endif
-           ")";
+    return "snappy_hip 0.5 (gfx950; Snappy 1.1.8 bit-exact; built with clang " SZ_STR(__clang_major__) "." SZ_STR(__clang_minor__) "." SZ_STR(__clang_patchlevel__)
+           ", " SZ_TOOLCHAIN "; src " SZ_SOURCE_ID ")";
 }
 
 const char *sz_strerror(int code)

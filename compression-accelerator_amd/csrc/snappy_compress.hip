@@ -1711,7 +1711,7 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                                 if (!no_cut) {
                                     // the same exit for a visit that ends before lane `cut`: the last start below it, and either
                                     // its hit lies below the cut too (then nothing changes for it) or the scan is open there
-                                    cut = bad_cut ? e + 1 : cut;
+                                    cut = bad_cut ? (e < 62u ? e + 1u : 63u) : cut;  // (<= 63: `1ull << cut` and below63(cut) below; the block is poisoned anyway)
                                     const uint64_t bl = below63(cut);
                                     const uint64_t Sx = S & bl, Hm_t = Hm & bl;
                                     const uint32_t sl = 63u - (uint32_t)__builtin_clzll(Sx | 1ull);
@@ -2289,7 +2289,11 @@ __device__ __forceinline__ uint32_t block_length(const uint32_t *__restrict__ in
 // tools/patches/route_mode.patch, EXPERIMENTS.md section 4.1.2.)
 __global__ __launch_bounds__(64) void reset_launch_state_kernel(uint32_t *__restrict__ select)
 {
-    if (threadIdx.x < 15)  // (select[15], the arrival counter of the sample's workgroups, is zero between launches by itself)
+    // All 16 words, the arrival counter of the sample's workgroups (select[15]) too: it returns to zero by itself after
+    // every sampled launch that runs to its end, but one that did not -- an aborted launch -- would make every later
+    // sample on this workspace elect its last workgroup early; a launch with a kernel named by the caller is the one
+    // place where no sample is in flight on the stream.
+    if (threadIdx.x < 16)
         select[threadIdx.x] = 0;
 }
 

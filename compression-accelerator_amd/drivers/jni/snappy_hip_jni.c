@@ -1,6 +1,9 @@
 /* snappy_hip_jni.c -- JNI shim of SnappyHip.scala: one C-ABI call per native method, no other logic.
- * NOT COMPILED IN THIS REPOSITORY (no jni.h in the build image): see SnappyHip.scala for the two build commands.
- * tests/test_abi.py checks that every sz_* symbol used here is declared in include/snappy_hip.h. */
+ * Built for a JVM with the two commands in SnappyHip.scala (needs a JDK's jni.h: there is none in the build image).
+ * In this repository the file is compiled and EXECUTED against a stand-in header, tests/jni_stub/jni.h, by a C program
+ * that plays the JVM (tests/jni_stub/jni_driver.c: faked direct buffers; tests/test_abi.py runs the argument checks on
+ * the CPU, tests/test_gpu_boundary.py::test_jni_shim_executes_on_the_gpu the round trips on the GPU); the Scala side
+ * is not run.  tests/test_abi.py also checks that every sz_* symbol used here is declared in include/snappy_hip.h. */
 #include <jni.h>
 #include <stdint.h>
 

@@ -24,9 +24,36 @@
 
 #include "snappy_hip.h"
 
-#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 3; } } while (0)
-#define CHECK_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); return 4; } } while (0)
-#define CHECK_SZ(x) do { int c_ = (x); if (c_ != SZ_OK) { fprintf(stderr, "%s: %s\n", #x, sz_strerror(c_)); return 5; } } while (0)
+/* A rank that fails after the communicator exists ABORTS it on its way out (ncclCommAbort): its peers then get an
+ * error from ncclCommInitRank / ncclAllGather instead of waiting for this rank for ever. */
+static ncclComm_t g_comm;
+static int g_comm_up;
+static int leave(int code)
+{
+    if (g_comm_up) {
+        g_comm_up = 0;
+        (void)ncclCommAbort(g_comm);
+    }
+    return code;
+}
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return leave(3); } } while (0)
+#define CHECK_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); return leave(4); } } while (0)
+#define CHECK_SZ(x) do { int c_ = (x); if (c_ != SZ_OK) { fprintf(stderr, "%s: %s\n", #x, sz_strerror(c_)); return leave(5); } } while (0)
+
+/* What a rank HAD, published beside its lengths (bench.py's verify_gather does the same): rank, number of blocks, sum
+ * and a position-weighted checksum of its lengths.  Every rank compares each peer's tag with the slice it received. */
+static void tag_of(const uint32_t *lens, uint64_t n, uint32_t rank, uint64_t tag[4])
+{
+    uint64_t sum = 0, chk = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        sum += lens[k];
+        chk = (chk + (uint64_t)lens[k] * (k + 1)) % 2305843009213693951ull;
+    }
+    tag[0] = rank;
+    tag[1] = n;
+    tag[2] = sum;
+    tag[3] = chk;
+}
 
 static int share_id(ncclUniqueId *id, const char *path, int rank)
 {
@@ -92,12 +119,17 @@ int main(int argc, char **argv)
     }
     uint8_t *d_src, *d_slots;
     uint32_t *d_in_len, *d_len, *d_all;
+    uint64_t *d_tag, *d_tags;
     CHECK_HIP(hipMalloc((void **)&d_src, ((size_t)mine + 1) * SZ_BLOCK_SIZE));
     CHECK_HIP(hipMalloc((void **)&d_slots, ((size_t)mine + 1) * SZ_SLOT_STRIDE));
     CHECK_HIP(hipMalloc((void **)&d_in_len, ((size_t)mine + 1) * 4));
     CHECK_HIP(hipMalloc((void **)&d_len, (size_t)per * 4));
     CHECK_HIP(hipMalloc((void **)&d_all, (size_t)per * world * 4));
+    CHECK_HIP(hipMalloc((void **)&d_tag, 4 * 8));
+    CHECK_HIP(hipMalloc((void **)&d_tags, (size_t)world * 4 * 8));
     CHECK_HIP(hipMemsetAsync(d_len, 0, (size_t)per * 4, stream));  /* (the padding of a short shard gathers as 0) */
+    CHECK_HIP(hipMemsetAsync(d_all, 0xff, (size_t)per * world * 4, stream));  /* what did not arrive reads as a marker, never as a length */
+    CHECK_HIP(hipMemsetAsync(d_tags, 0xff, (size_t)world * 4 * 8, stream));
     CHECK_HIP(hipMemcpyAsync(d_src, h_src, (size_t)mine * SZ_BLOCK_SIZE, hipMemcpyHostToDevice, stream));
     CHECK_HIP(hipMemcpyAsync(d_in_len, h_in_len, (size_t)mine * 4, hipMemcpyHostToDevice, stream));
 
@@ -110,8 +142,9 @@ int main(int argc, char **argv)
         fprintf(stderr, "rank %u: no RCCL unique id through %s\n", rank, argv[4]);
         return 4;
     }
-    ncclComm_t comm;
-    CHECK_NCCL(ncclCommInitRank(&comm, (int)world, id, (int)rank));
+    CHECK_NCCL(ncclCommInitRank(&g_comm, (int)world, id, (int)rank));
+    g_comm_up = 1;
+    const ncclComm_t comm = g_comm;
 
     /* the hot path: bodies + lengths of this rank's blocks, no data-path collective */
     CHECK_SZ(sz_compress_blocks_hip(d_src, SZ_BLOCK_SIZE, d_in_len, mine, d_slots, SZ_SLOT_STRIDE, d_len, 0, stream));
@@ -122,15 +155,20 @@ int main(int argc, char **argv)
     CHECK_HIP(hipMemcpyAsync(h_pad, d_all, (size_t)per * world * 4, hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipMemcpyAsync(h_mine, d_len, (size_t)mine * 4, hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
+    /* outside the path: every rank publishes the tag of what it had (a second, 32-byte all-gather) */
+    uint64_t my_tag[4], *h_tags = (uint64_t *)malloc((size_t)world * 4 * 8);
+    tag_of(h_mine, mine, rank, my_tag);
+    CHECK_HIP(hipMemcpyAsync(d_tag, my_tag, sizeof my_tag, hipMemcpyHostToDevice, stream));
+    CHECK_NCCL(ncclAllGather(d_tag, d_tags, 4, ncclUint64, comm, stream));
+    CHECK_HIP(hipMemcpyAsync(h_tags, d_tags, (size_t)world * 4 * 8, hipMemcpyDeviceToHost, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
     uint32_t ranks_seen = 0;
     for (uint32_t r = 0; r < world; r++) {  /* drop the padding: rank r's shard is [rb, re) */
-        uint64_t rb, re;
+        uint64_t rb, re, got[4];
         CHECK_SZ(sz_shard_range(n_blocks_total, r, world, &rb, &re));
         memcpy(h_all + rb, h_pad + (size_t)r * per, (size_t)(re - rb) * 4);
-        int live = re == rb;  /* (an empty shard has nothing to show) */
-        for (uint64_t k = rb; k < re; k++)
-            live |= h_all[k] != 0;
-        ranks_seen += live ? 1u : 0u;
+        tag_of(h_all + rb, re - rb, r, got);  /* counted, not inferred: the slice that ARRIVED against the tag its rank SENT */
+        ranks_seen += memcmp(got, h_tags + (size_t)r * 4, sizeof got) == 0 ? 1u : 0u;
     }
     /* layout of the whole stream; refuses the kernels' markers */
     uint64_t *offsets = (uint64_t *)malloc(((size_t)n_blocks_total + 1) * 8), bad = 0, sum = 0;
@@ -154,6 +192,7 @@ int main(int argc, char **argv)
         printf("%s%u", k ? ", " : "", h_all[k]);
     printf("]}\n");
 
+    g_comm_up = 0;
     ncclCommDestroy(comm);
     (void)sz_release_stream_resources(stream);
     (void)hipStreamDestroy(stream);

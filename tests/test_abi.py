@@ -22,10 +22,11 @@ def _declared_symbols():
 
 
 def test_jni_shim_uses_only_the_declared_abi():
-    """compression-accelerator_amd/drivers/jni/ (the north star's Scala/JVM driver) cannot be compiled here -- no JDK,
-    no jni.h --, so at least its contact with the library is pinned: every sz_* function the shim calls and every
+    """compression-accelerator_amd/drivers/jni/ (the north star's Scala/JVM driver): there is no JDK here, so the Scala
+    side is never compiled; its contact with the library is pinned -- every sz_* function the shim calls and every
     SZ_* constant it names is declared in include/snappy_hip.h, every native method of SnappyHip.scala has its
-    Java_snappyhip_SnappyHip_00024_<name> in the shim and the other way round."""
+    Java_snappyhip_SnappyHip_00024_<name> in the shim and the other way round.  (The C side IS compiled and run,
+    against a stand-in jni.h: test_jni_shim_argument_checks_run below, test_gpu_boundary.py on the GPU.)"""
     jdir = os.path.join(ROOT, "compression-accelerator_amd", "drivers", "jni")
     c = open(os.path.join(jdir, "snappy_hip_jni.c")).read()
     c = re.sub(r"/\*.*?\*/", "", c, flags=re.S)
@@ -40,6 +41,16 @@ def test_jni_shim_uses_only_the_declared_abi():
     natives = set(re.findall(r"@native\s+def\s+(\w+)", scala))
     shims = set(re.findall(r"Java_snappyhip_SnappyHip_00024_(\w+)\s*\(", c))
     assert natives == shims and len(natives) >= 4, natives ^ shims
+
+
+def test_jni_shim_argument_checks_run(tmp_path):
+    """The shim's own logic -- sign, bound and capacity checks, the varint probe, the long[] it returns -- executed:
+    snappy_hip_jni.c built (-Wall -Werror) against tests/jni_stub/jni.h, driven by tests/jni_stub/jni_driver.c with faked
+    direct buffers.  Every case here returns before a kernel would be launched, so it needs no GPU."""
+    import json
+    exe = build_util.cc_jni(str(tmp_path / "jni_driver"))
+    out = json.loads(subprocess.check_output([exe, "args", str(tmp_path)]).decode())
+    assert out == build_util.JNI_ARGUMENT_CASES, out
 
 
 def test_library_exports_every_declared_symbol():
@@ -57,6 +68,20 @@ def test_library_exports_every_declared_symbol():
     assert exported == set(declared), exported ^ set(declared)
     hdr = open(os.path.join(ROOT, "include", "snappy_hip.h")).read()
     assert hdr.count("SZ_API ") == len(declared) + 1, "every declaration carries SZ_API (+ its definition)"
+
+
+def test_library_was_built_from_this_tree():
+    """sz_version() names the sources the library was built from; the same hash, recomputed (tests/build_util.py),
+    must come out of csrc/ + include/ as they are now -- a stale .so cannot pass for HEAD's.  `make source_id`
+    agrees with both."""
+    P = load_package()
+    ver = P.lib().sz_version().decode()
+    sid = build_util.source_id()
+    assert re.search(r"src [0-9a-f]{16}\)$", ver), ver
+    assert "src " + sid in ver, (ver, sid)
+    made = subprocess.check_output(["make", "-s", "-C", build_util.CSRC, "source_id"]).decode().split()[-1]
+    assert made == sid
+    assert ("untuned toolchain" in ver) == ("HIP 7.2.26015" not in ver)
 
 
 def test_no_torch_or_oracle_in_the_abi_library():

@@ -174,6 +174,42 @@ def test_rocc_driver_program(tmp_path):
     assert open(out, "rb").read() == oracle_lib.raw_compress(fuzzgen.corpus("fox"))
 
 
+def test_jni_shim_executes_on_the_gpu(tmp_path):
+    """The C side of the north star's Scala/JVM driver (drivers/jni/snappy_hip_jni.c), EXECUTED: built against the
+    stand-in tests/jni_stub/jni.h and called by tests/jni_stub/jni_driver.c the way a JVM calls it -- direct buffers in,
+    the RoCC command pair (SET_LENGTH, COMPRESS -> rd; SET_LENGTH, UNCOMPRESS -> rd) of tests/compression.c:20-39 inside.
+    thistle 130 -> 112, fox == the oracle's bytes, a ragged multi-fragment text, round trips, a damaged stream
+    (rd != 0), a dst one byte short (SZ_ENOSPC), and the device-pointer entry on blocks resident in HBM."""
+    exe = build_util.cc_jni(str(tmp_path / "jni_driver"))
+    thistle = (b"If Tid the thistle sifter lifts his sieve of sifted thistles, then he'll shift "
+               b"the thistles in his sifting sieve to live unsifted.")
+    inputs = [fuzzgen.corpus("mtg")[1000:1000 + 65536 * 3 + 1234], thistle, fuzzgen.corpus("fox"),
+              fuzzgen.tiled_block(fuzzgen.corpus("random_ascii"), 1)]
+    paths = []
+    for k, b in enumerate(inputs):
+        paths.append(str(tmp_path / ("in%d.bin" % k)))
+        open(paths[-1], "wb").write(b)
+    r = subprocess.run([exe, "gpu", str(tmp_path)] + paths, capture_output=True, timeout=170)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = json.loads(r.stdout.decode())
+    for key, want in build_util.JNI_ARGUMENT_CASES.items():
+        assert out[key] == want, key
+    for k, (b, f) in enumerate(zip(inputs, out["files"])):
+        want = oracle_lib.raw_compress(b)
+        assert f["n"] == len(b) and f["compressed"] == len(want), (k, f)
+        assert open(str(tmp_path / ("%d.snappy" % k)), "rb").read() == want, "file %d: compress() through the JNI shim differs from the oracle" % k
+        assert f["uncompress_rd"] == 0 and f["round_trip"] is True
+        assert f["damaged_rd"] not in (0, -1), f  # rd != 0 on failure (tests/compression.c:30), or SZ_ECORRUPT from the probe
+        assert f["tight_dst"] == -28
+    assert out["files"][1]["compressed"] == 112 and out["files"][2]["compressed"] == 2407
+    dev = out["device"]
+    assert dev["rc"] == 0 and dev["rc_tight_stride"] == -28 and dev["blocks"] == 3
+    for b in range(3):
+        want = oracle_lib.raw_compress(inputs[0][b * 65536:(b + 1) * 65536])
+        assert dev["lens"][b] == len(want)
+        assert open(str(tmp_path / ("dev_%d.snappy" % b)), "rb").read() == want
+
+
 def test_sw_benchmark_driver_reproduces_reference_sizes(tmp_path):
     exe = build_util.cxx(os.path.join(build_util.DRIVERS, "sw_benchmark.cc"), str(tmp_path / "sw_benchmark"))
     with open(os.path.join(G, "sw_results_sizes.json")) as f:

@@ -60,15 +60,16 @@ def _run_c_ranks(tmp_path, world, data):
     procs = [subprocess.Popen([exe, str(inp), str(world), str(r), idf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
              for r in range(world)]
     outs = []
-    for r, p in enumerate(procs):
-        try:
+    try:
+        for r, p in enumerate(procs):
             out, err = p.communicate(timeout=300)
-        except subprocess.TimeoutExpired:
-            for q in procs:
+            assert p.returncode == 0, "rank %d of the C caller failed (rc %d)\n%s" % (r, p.returncode, err.decode()[-3000:])
+            outs.append(json.loads(out.decode().strip().splitlines()[-1]))
+    finally:  # whatever happened -- a rank that failed, a timeout --: no rank is left behind holding a GPU
+        for q in procs:
+            if q.poll() is None:
                 q.kill()
-            raise
-        assert p.returncode == 0, "rank %d of the C caller failed (rc %d)\n%s" % (r, p.returncode, err.decode()[-3000:])
-        outs.append(json.loads(out.decode().strip().splitlines()[-1]))
+                q.wait()
     return outs
 
 

@@ -52,6 +52,14 @@ def test_native_library_is_loaded_and_sees_the_gpu():
     assert os.path.exists(P.LIB_PATH)
     with open("/proc/self/maps") as f:
         assert "libsnappy_hip.so" in f.read()
+    # ... and it is THIS tree's library: the box loads whatever .so was pushed, so the identity of the sources it was
+    # built from (csrc/Makefile SOURCE_ID, inside sz_version()) is recomputed from the sources beside it
+    import build_util
+    ver = P.lib().sz_version().decode()
+    assert "src " + build_util.source_id() in ver, \
+        "libsnappy_hip.so was not built from this tree's csrc/ + include/ (%s; sources: %s): run make" % (
+            ver, build_util.source_id())
+    print(ver)
 
 
 def test_edge_sizes_all_kinds():

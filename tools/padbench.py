@@ -3,7 +3,7 @@
 The build pads a tile with 64 independent vector (0x1000 / 0x2000 / 0x4000) or scalar (0x10000 / 0x20000 / 0x40000)
 instructions in the lone waves' tile loop / off the token's path of a team's turn / on it (csrc/diag.h: ABLATION_PAD);
 output bytes unchanged.  Interleaved launches on one pair of buffers; prints the rate per setting and the slowdown per
-64 instructions (EXPERIMENTS.md R5.4)."""
+64 instructions (EXPERIMENTS.md R5.3)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
