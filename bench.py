@@ -379,6 +379,48 @@ def hw_compat_row(P, kind, n_blocks, device, reps=3):
             "what": "functional model of the reference accelerator's datapath (size-exact on 31 of 36 hw_results.csv rows)"}
 
 
+def host_api_rates(P, n_bytes, reps=3):
+    """The reference's own call surface (snappy::Compress / RawCompress / Uncompress on host memory: tests/swcompression.cc:45,
+    workloads/snappy/overlay/root/compress.cc:17 -> sz_compress / sz_uncompress), PCIe included, on pageable host buffers
+    of n_bytes: median wall time of `reps` calls after one warm-up call (which allocates the thread's workspace).  Never
+    `value`: the bench's metric is the kernel path with its input resident in HBM.  Bytes checked against the oracle."""
+    import ctypes
+    import numpy as np
+    import oracle_lib
+    L = P.lib()
+    out = {"bytes": n_bytes, "calls": reps,
+           "what": "sz_compress / sz_uncompress on pageable host memory, wall clock, PCIe both ways included: a pipeline of 64..256 MiB "
+                   "stages (copy in | compress + pack | copy out) with the caller's buffers registered for DMA for the length of the call"}
+    cap = P.max_compressed_length(n_bytes)
+    dst = np.empty(cap, dtype=np.uint8)
+    back = np.empty(n_bytes, dtype=np.uint8)
+    got = ctypes.c_size_t(0)
+    for kind, name in (("c3", "incompressible"), ("text", "text")):
+        src = make_input(kind, 0, n_bytes // BLOCK, "cpu").numpy()
+        ts = []
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            rc = L.sz_compress(src.ctypes.data, n_bytes, dst.ctypes.data, cap, ctypes.byref(got))
+            ts.append(time.perf_counter() - t0)
+            assert rc == 0, rc
+        clen = got.value
+        tu = []
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            rc = L.sz_uncompress(dst.ctypes.data, clen, back.ctypes.data, n_bytes, ctypes.byref(got))
+            tu.append(time.perf_counter() - t0)
+            assert rc == 0, rc
+        want = oracle_lib.raw_compress(src)
+        out[name] = {"compress_GBps": round(n_bytes / sorted(ts[1:])[len(ts[1:]) // 2] / 1e9, 2),
+                     "uncompress_GBps": round(n_bytes / sorted(tu[1:])[len(tu[1:]) // 2] / 1e9, 2),
+                     "first_call_ms": round(ts[0] * 1e3, 1), "stream_bytes": clen,
+                     "bytes_equal_oracle": bool(clen == len(want) and dst[:clen].tobytes() == want),
+                     "round_trip": bool(np.array_equal(back, src))}
+        del src, want
+    L.sz_release_thread_resources()
+    return out
+
+
 def copy_roof(n_bytes, device, reps=10):
     """A plain device-to-device copy of as many bytes as the headline workload reads (torch's copy kernel, the
     same process, the same box, HIP events on the stream it runs on): what this part moves when a kernel
@@ -629,10 +671,12 @@ def rank_main(args):
                            "kernel_ms": round(float(np.mean(r["kernel_ms"])), 3), "kernel": r["kernel_name"],
                            "blocks_differing_from_oracle": r["blocks_differing_from_oracle"]}
 
-    stream_row = hw_row = None
+    stream_row = hw_row = host_row = None
     if not args.no_extra and rank == 0 and world == 1:
         stream_row = one_stream(P, "text", 16384, device)
         hw_row = hw_compat_row(P, "text", 16384, device)  # (two rounds of its 8 192 wave slots)
+        torch.cuda.empty_cache()
+        host_row = host_api_rates(P, 2 << 30)  # (tools/hostrate.py: the same size through the snappy:: facade, both call shapes)
 
     bad_all = (main_res["blocks_differing_from_oracle"] + sum(v["blocks_differing_from_oracle"] for v in extras.values())
                + sum(v["blocks_differing_from_oracle"] for v in large.values()))
@@ -692,6 +736,7 @@ def rank_main(args):
             "workloads_at_4x_size": large,
             "one_stream": stream_row,
             "hw_compat": hw_row,
+            "host_api": host_row,
         }
         if main_res["layout"] is not None:
             line.update(main_res["layout"])  # rank 0's view of the all_gather result

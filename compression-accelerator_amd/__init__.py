@@ -31,7 +31,8 @@ ROCC_CHANNEL, ROCC_COMPRESS, ROCC_UNCOMPRESS, ROCC_SET_LENGTH = 3, 0, 1, 2
 ABI_SYMBOLS = (
     "sz_max_compressed_length", "sz_compress_blocks_hip", "sz_compress_stream_hip", "sz_pack_stream_hip",
     "sz_uncompress_blocks_hip", "sz_uncompress_packed_hip", "sz_uncompress_stream_work_bytes",
-    "sz_uncompress_stream_hip", "sz_compress", "sz_uncompress", "sz_get_uncompressed_length",
+    "sz_uncompress_stream_hip", "sz_compress", "sz_compress_begin", "sz_compress_finish", "sz_uncompress",
+    "sz_get_uncompressed_length",
     "sz_rocc_cmd", "rocc_cmd", "sz_rocc_last_error", "sz_release_thread_resources",
     "sz_release_stream_resources", "sz_shard_range", "sz_stream_offsets", "sz_device_count",
     "sz_last_hip_error", "sz_strerror", "sz_version", "sz_profile_next_launch",
@@ -83,6 +84,10 @@ def lib():
     L.sz_uncompress_stream_hip.restype = i32
     L.sz_compress.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
     L.sz_compress.restype = i32
+    L.sz_compress_begin.argtypes = [vp, sz]
+    L.sz_compress_begin.restype = i32
+    L.sz_compress_finish.argtypes = [vp, sz, ctypes.POINTER(sz)]
+    L.sz_compress_finish.restype = i32
     L.sz_uncompress.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
     L.sz_uncompress.restype = i32
     L.sz_get_uncompressed_length.argtypes = [vp, sz, ctypes.POINTER(sz)]

@@ -197,6 +197,42 @@ inline int hip_fail(hipError_t e)
             return hip_fail(e_);       \
     } while (0)
 
+// The caller's (pageable) buffer made DMA-able in place for the length of one call.  A copy to or from pageable memory
+// goes through the runtime's own staging buffers on the calling thread -- it is not asynchronous, and the copy in and
+// the copy out of one call cannot overlap; a registered range is copied by the DMA engines alone (tools/hostxfer.hip:
+// 57 GB/s each way, 49 both at once; registering costs less than the copy it enables).  Registration can fail -- a
+// read-only mapping, a range the caller has registered already, a platform without it --: then `ok` is false and the
+// copies are the runtime's pageable ones, correct and slower.  Always released before the call returns: a registration
+// must not outlive the caller's right to the memory.
+struct HostPin {
+    void *p = nullptr;
+    bool ok = false;
+    HostPin(const void *ptr, size_t n, bool read_only)
+    {
+        if (!ptr || n == 0 || getenv("SZ_NO_HOST_REGISTER"))
+            return;
+        void *q = const_cast<void *>(ptr);
+        hipError_t e = hipHostRegister(q, n, hipHostRegisterDefault);
+        if (e != hipSuccess && read_only) {
+            (void)hipGetLastError();
+            e = hipHostRegister(q, n, hipHostRegisterReadOnly);
+        }
+        if (e == hipSuccess) {
+            p = q;
+            ok = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    ~HostPin()
+    {
+        if (ok)
+            (void)hipHostUnregister(p);
+    }
+    HostPin(const HostPin &) = delete;
+    HostPin &operator=(const HostPin &) = delete;
+};
+
 // Grow-only device workspace of the host-buffer API, one per host thread (one RoCC port per hart).
 struct Workspace {
     hipStream_t stream = nullptr;
@@ -204,6 +240,54 @@ struct Workspace {
     size_t cap[5] = {0, 0, 0, 0, 0};
     int device = -1;
     std::vector<uint8_t> host;  // staging of the one-fragment path (slot + length in one copy)
+    // the pipeline of large host buffers (compress_pipelined): copies in and out on streams of their own, one event per
+    // chunk and direction, the chunks' running totals in pinned memory
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> ev;
+    uint64_t *pin_tot = nullptr;
+    static constexpr size_t kPinTot = 64;
+    // a call between sz_compress_begin and sz_compress_finish (sz_compress is the two back to back)
+    struct Pending {
+        bool active = false, enqueued = false;
+        const uint8_t *src = nullptr;
+        size_t n = 0, nh = 0;
+        uint8_t hdr[5] = {0, 0, 0, 0, 0};
+        uint32_t stages = 0;
+        std::unique_ptr<HostPin> pin_src;
+        void clear()
+        {
+            pin_src.reset();
+            active = enqueued = false;
+            src = nullptr;
+            n = nh = 0;
+            stages = 0;
+        }
+    } pending;
+
+    int ensure_pipeline(size_t n_events)
+    {
+        if (!s_in)
+            SZ_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+        if (!s_out)
+            SZ_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+        if (!pin_tot)
+            SZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&pin_tot), kPinTot * sizeof(uint64_t), hipHostMallocDefault));
+        while (ev.size() < n_events) {
+            hipEvent_t e = nullptr;
+            SZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev.push_back(e);
+        }
+        return SZ_OK;
+    }
+    void sync_all()  // every path out of a pipelined call, errors included: nothing of it is in flight any more
+    {
+        if (s_in)
+            (void)hipStreamSynchronize(s_in);
+        if (stream)
+            (void)hipStreamSynchronize(stream);
+        if (s_out)
+            (void)hipStreamSynchronize(s_out);
+    }
 
     int ensure_stream()
     {
@@ -239,8 +323,20 @@ struct Workspace {
             buf[i] = nullptr;
             cap[i] = 0;
         }
+        sync_all();
+        pending.clear();  // (a call begun and never finished: its work is drained, the caller's memory let go)
+        for (hipEvent_t e : ev)
+            (void)hipEventDestroy(e);
+        ev.clear();
+        if (pin_tot)
+            (void)hipHostFree(pin_tot);
+        pin_tot = nullptr;
+        if (s_in)
+            (void)hipStreamDestroy(s_in);
+        if (s_out)
+            (void)hipStreamDestroy(s_out);
+        s_in = s_out = nullptr;
         if (stream) {
-            (void)hipStreamSynchronize(stream);
             drop_dual_scratch(device, stream);
             (void)hipStreamDestroy(stream);
         }
@@ -252,6 +348,35 @@ struct Workspace {
 // host-buffer API or the RoCC surface calls sz_release_thread_resources() before it ends (snappy_hip.h).
 thread_local Workspace tl_ws;
 
+// The stages of the pipeline, in input bytes (multiples of 64 KiB but the last).  The first copy in and the last
+// compress + copy out are the parts of a call that nothing overlaps, so the stages start small (64 MiB), double up to
+// 256 MiB -- a compressible stage of 4 096 fragments is a launch the persistent kernel takes at 63 GB/s, above the
+// link's 50; one of 1 024 fragments gets 36, one of 512 only 20 -- and come down again towards the end: a stage takes
+// at most a third of what is left.  2 GiB: 64 64 128 256 x 4 128 128 64 x 4 MiB.
+constexpr size_t kPipelineMinBytes = (size_t)128 << 20;
+constexpr size_t kStageMin = (size_t)64 << 20, kStageMax = (size_t)256 << 20;
+std::vector<size_t> pipeline_stages(size_t n)
+{
+    std::vector<size_t> st;
+    if (n < kPipelineMinBytes) {
+        st.push_back(n);
+        return st;
+    }
+    size_t rem = n, ramp = kStageMin;
+    while (rem) {
+        size_t s = kStageMin;
+        while (s * 2 <= rem / 3 && s * 2 <= kStageMax && s * 2 <= ramp)
+            s *= 2;
+        if (rem <= s + kStageMin / 2)
+            s = rem;
+        st.push_back(s);
+        rem -= s;
+        if (st.size() >= 2 && ramp < kStageMax)
+            ramp *= 2;
+    }
+    return st;
+}
+
 size_t put_varint32(uint8_t *dst, uint32_t v)
 {
     size_t k = 0;
@@ -262,6 +387,18 @@ size_t put_varint32(uint8_t *dst, uint32_t v)
     dst[k++] = (uint8_t)v;
     return k;
 }
+
+#ifdef SZ_HOST_TIMING  // diagnostic builds: where a pipelined call's time goes, to stderr
+#include <chrono>
+#define HOST_T(v) const double v = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count()
+#else
+#define HOST_T(v) ((void)0)
+#endif
+
+struct SyncOnExit {  // declared after the HostPins of a call: runs before they release the caller's memory
+    Workspace &ws;
+    ~SyncOnExit() { ws.sync_all(); }
+};
 
 }  // namespace
 
@@ -511,30 +648,132 @@ int sz_get_uncompressed_length(const void *src, size_t n, size_t *result)
     return SZ_ECORRUPT;
 }
 
-int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len)
+// One stage for inputs below 128 MiB, otherwise a pipeline of 64..256 MiB stages:
+//   s_in:    copy in of stage k+1 ...
+//   stream:  ... under fragments of stage k compressed into slots, packed behind stage k-1's bytes (the base comes
+//            from device memory: no host in between), stage k's running total copied to pinned memory ...
+//   s_out:   ... under the copy out of stage k-1, straight to its final place in `dst`.
+// sz_compress_begin enqueues everything that does not need `dst` (0.3 ms of host time for 2 GiB); sz_compress_finish
+// waits for one event per stage (it needs the total to know what to copy out and whether it fits), issues the copies
+// out and synchronises everything once, at the end.  (Round 5: one copy in, kernels, a synchronisation, one copy out, a
+// synchronisation, all on pageable memory: 15 GB/s on incompressible data, 9 on text, PCIe included.)
+int sz_compress_begin(const void *src, size_t n)
 {
-    if (!dst || !out_len || (n && !src) || n > 0xffffffffull)
+    if ((n && !src) || n > 0xffffffffull)
         return SZ_EINVAL;
-    uint8_t hdr[5];
-    const size_t nh = put_varint32(hdr, (uint32_t)n);
-    if (dst_cap < nh)
-        return SZ_ENOSPC;
     if (sz_device_count() < 1)  // fail loudly: there is no CPU fallback
         return SZ_ENODEV;
-    memcpy(dst, hdr, nh);
+    Workspace &ws = tl_ws;
+    Workspace::Pending &p = ws.pending;
+    if (p.active)
+        return SZ_EINVAL;  // one call in flight per host thread (one RoCC port per hart, cmd.ready := !busy)
+    int rc = ws.ensure_stream();
+    if (rc)
+        return rc;
+    p.clear();
+    p.src = static_cast<const uint8_t *>(src);
+    p.n = n;
+    p.nh = put_varint32(p.hdr, (uint32_t)n);
+    p.active = true;
+    if (n <= SZ_BLOCK_SIZE)  // nothing or one fragment: all of it in sz_compress_finish, behind one synchronisation
+        return SZ_OK;
+    struct Undo {  // an error on the way: nothing of the call stays in flight, the caller's memory is let go
+        Workspace &ws;
+        bool armed = true;
+        ~Undo()
+        {
+            if (armed) {
+                ws.sync_all();
+                ws.pending.clear();
+            }
+        }
+    } undo{ws};
+    HOST_T(t_0);
+    const uint32_t nb = (uint32_t)((n + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
+    const size_t stride = SZ_SLOT_STRIDE;
+    const std::vector<size_t> stages = pipeline_stages(n);
+    const uint32_t K = (uint32_t)stages.size();
+    size_t longest = 0;
+    for (size_t b : stages)
+        longest = b > longest ? b : longest;
+    const uint32_t cb = (uint32_t)((longest + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);  // fragments of the longest stage
+    if (K > Workspace::kPinTot)
+        return SZ_EINVAL;  // (cannot happen: n < 2^32 gives fewer than 30 stages)
+    if ((rc = ws.reserve(0, n)) || (rc = ws.reserve(1, (size_t)cb * stride)) ||
+        (rc = ws.reserve(2, (size_t)nb * sizeof(uint32_t))) ||
+        (rc = ws.reserve(3, ((size_t)nb + K) * sizeof(uint64_t))) ||
+        (rc = ws.reserve(4, sz_max_compressed_length(n) + 16)) || (rc = ws.ensure_pipeline(2 * (size_t)K)))
+        return rc;
+    uint8_t *d_in = static_cast<uint8_t *>(ws.buf[0]);
+    uint8_t *d_slots = static_cast<uint8_t *>(ws.buf[1]);
+    uint32_t *d_len = static_cast<uint32_t *>(ws.buf[2]);
+    uint64_t *d_off = static_cast<uint64_t *>(ws.buf[3]);  // stage k: its fragments' offsets + 1 entry (its running total), one stage behind the other
+    uint8_t *d_packed = static_cast<uint8_t *>(ws.buf[4]);
+    if (K > 1)
+        p.pin_src.reset(new HostPin(src, n, true));
+    HOST_T(t_1);
+    size_t o = 0, first_frag = 0;
+    const uint64_t *prev_total = nullptr;
+    for (uint32_t k = 0; k < K; k++) {
+        const size_t bytes = stages[k];
+        const uint32_t nbk = (uint32_t)((bytes + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
+        uint64_t *off_k = d_off + first_frag + k;
+        SZ_HIP(hipMemcpyAsync(d_in + o, p.src + o, bytes, hipMemcpyHostToDevice, ws.s_in));
+        SZ_HIP(hipEventRecord(ws.ev[2 * k], ws.s_in));
+        SZ_HIP(hipStreamWaitEvent(ws.stream, ws.ev[2 * k], 0));
+        if ((rc = sz_compress_stream_hip(d_in + o, bytes, d_slots, stride, d_len + first_frag, 0, ws.stream)))
+            return rc;
+        SZ_HIP(szk::launch_pack_stream(d_slots, stride, d_len + first_frag, nbk, p.nh, d_packed, off_k, ws.stream, prev_total));
+        SZ_HIP(hipMemcpyAsync(ws.pin_tot + k, off_k + nbk, sizeof(uint64_t), hipMemcpyDeviceToHost, ws.stream));
+        SZ_HIP(hipEventRecord(ws.ev[2 * k + 1], ws.stream));
+        prev_total = off_k + nbk;
+        o += bytes;
+        first_frag += nbk;
+    }
+#ifdef SZ_HOST_TIMING
+    HOST_T(t_2);
+    fprintf(stderr, "sz_compress_begin %zu bytes, %u stages (src registered: %d): reserve + register %.2f ms, enqueue %.2f ms\n", n, K,
+            (int)(p.pin_src && p.pin_src->ok), t_1 - t_0, t_2 - t_1);
+#endif
+    p.stages = K;
+    p.enqueued = true;
+    undo.armed = false;
+    return SZ_OK;
+}
+
+int sz_compress_finish(void *dst, size_t dst_cap, size_t *out_len)
+{
+    Workspace &ws = tl_ws;
+    Workspace::Pending &p = ws.pending;
+    if (!p.active)
+        return SZ_EINVAL;
+    struct Done {  // every way out: nothing of the call in flight, the caller's memory let go, the thread free for the next call
+        Workspace &ws;
+        ~Done()
+        {
+            if (ws.pending.enqueued)
+                ws.sync_all();
+            ws.pending.clear();
+        }
+    } done_guard{ws};
+    if (!dst && !out_len)
+        return SZ_OK;  // the call is abandoned
+    if (!dst || !out_len)
+        return SZ_EINVAL;
+    const size_t n = p.n, nh = p.nh;
+    if (dst_cap < nh)
+        return SZ_ENOSPC;
+    memcpy(dst, p.hdr, nh);
     if (n == 0) {
         *out_len = nh;
         return SZ_OK;
     }
-    Workspace &ws = tl_ws;
-    int rc = ws.ensure_stream();
-    if (rc)
-        return rc;
+    int rc;
     if (n <= SZ_BLOCK_SIZE) {
         // One fragment (what the RoCC surface sends: one buffer per COMPRESS command, 130 bytes in tests/compression.c):
         // the block's own raw stream -- varint + body, SZ_FLAG_BLOCK_VARINT -- IS snappy::Compress's output, so there is
         // nothing to pack, and length and bytes come back in ONE copy behind ONE synchronisation (the length sits right
-        // behind the slot): 67 -> ~40 us for 130 bytes against the general path below (two more kernels, a copy and a
+        // behind the slot): 67 -> ~40 us for 130 bytes against the general path (two more kernels, a copy and a
         // synchronisation for the length alone).
         const size_t bound = (sz_max_compressed_length(n) + 5 + 15) & ~(size_t)15;  // slot, and the offset of the length behind it
         if ((rc = ws.reserve(0, n)) || (rc = ws.reserve(1, bound + 16)))
@@ -542,7 +781,7 @@ int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *ou
         uint8_t *d_in = static_cast<uint8_t *>(ws.buf[0]);
         uint8_t *d_slot = static_cast<uint8_t *>(ws.buf[1]);
         ws.host.resize(bound + 16);
-        SZ_HIP(hipMemcpyAsync(d_in, src, n, hipMemcpyHostToDevice, ws.stream));
+        SZ_HIP(hipMemcpyAsync(d_in, p.src, n, hipMemcpyHostToDevice, ws.stream));
         if ((rc = sz_compress_blocks_hip(d_in, n, nullptr, 1, d_slot, bound, reinterpret_cast<uint32_t *>(d_slot + bound),
                                          SZ_FLAG_BLOCK_VARINT, ws.stream)))
             return rc;
@@ -558,35 +797,43 @@ int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *ou
         *out_len = len;
         return SZ_OK;
     }
-    const uint32_t nb = (uint32_t)((n + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
-    const size_t stride = SZ_SLOT_STRIDE;
-    if ((rc = ws.reserve(0, n)) || (rc = ws.reserve(1, (size_t)nb * stride)) ||
-        (rc = ws.reserve(2, (size_t)nb * sizeof(uint32_t))) ||
-        (rc = ws.reserve(3, ((size_t)nb + 1) * sizeof(uint64_t))) ||
-        (rc = ws.reserve(4, sz_max_compressed_length(n) + 16)))
-        return rc;
-    uint8_t *d_in = static_cast<uint8_t *>(ws.buf[0]);
-    uint8_t *d_slots = static_cast<uint8_t *>(ws.buf[1]);
-    uint32_t *d_len = static_cast<uint32_t *>(ws.buf[2]);
-    uint64_t *d_off = static_cast<uint64_t *>(ws.buf[3]);
+    HOST_T(t_0);
+    const uint32_t K = p.stages;
     uint8_t *d_packed = static_cast<uint8_t *>(ws.buf[4]);
-    SZ_HIP(hipMemcpyAsync(d_in, src, n, hipMemcpyHostToDevice, ws.stream));
-    if ((rc = sz_compress_stream_hip(d_in, n, d_slots, stride, d_len, 0, ws.stream)))
-        return rc;
-    if ((rc = sz_pack_stream_hip(d_slots, stride, d_len, nb, nh, d_packed, d_off, ws.stream)))
-        return rc;
-    uint64_t total = 0;
-    SZ_HIP(hipMemcpyAsync(&total, d_off + nb, sizeof(total), hipMemcpyDeviceToHost, ws.stream));
-    SZ_HIP(hipStreamSynchronize(ws.stream));
-    if (total == ~0ull)  // a fragment came back with an error marker instead of a length
-        return SZ_EHIP;
-    if (total > dst_cap)
-        return SZ_ENOSPC;
-    SZ_HIP(hipMemcpyAsync(static_cast<uint8_t *>(dst) + nh, d_packed + nh, total - nh,
-                          hipMemcpyDeviceToHost, ws.stream));
-    SZ_HIP(hipStreamSynchronize(ws.stream));
-    *out_len = (size_t)total;
+    uint8_t *h_dst = static_cast<uint8_t *>(dst);
+    const size_t bound = sz_max_compressed_length(n);
+    HostPin pin_dst(K > 1 ? dst : nullptr, dst_cap < bound ? dst_cap : bound, false);
+    SyncOnExit drain{ws};  // (declared after the pin: nothing is in flight any more when `dst` is let go)
+    HOST_T(t_1);
+    uint64_t done = nh;  // bytes of the stream that are in `dst`, or on their way there
+    for (uint32_t k = 0; k < K; k++) {
+        SZ_HIP(hipEventSynchronize(ws.ev[2 * k + 1]));
+        const uint64_t total = ws.pin_tot[k];
+        if (total == ~0ull)  // a fragment came back with an error marker instead of a length
+            return SZ_EHIP;
+        if (total > dst_cap)
+            return SZ_ENOSPC;
+        SZ_HIP(hipMemcpyAsync(h_dst + done, d_packed + done, total - done, hipMemcpyDeviceToHost, ws.s_out));
+        done = total;
+    }
+    SZ_HIP(hipStreamSynchronize(ws.s_out));
+#ifdef SZ_HOST_TIMING
+    HOST_T(t_2);
+    fprintf(stderr, "sz_compress_finish (dst registered: %d): register %.2f ms, drain %.2f ms\n", (int)pin_dst.ok, t_1 - t_0, t_2 - t_1);
+#endif
+    *out_len = (size_t)done;
     return SZ_OK;
+}
+
+int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len)
+{
+    if (!dst || !out_len || (n && !src) || n > 0xffffffffull)
+        return SZ_EINVAL;
+    uint8_t hdr[5];
+    if (dst_cap < put_varint32(hdr, (uint32_t)n))
+        return SZ_ENOSPC;
+    const int rc = sz_compress_begin(src, n);
+    return rc ? rc : sz_compress_finish(dst, dst_cap, out_len);
 }
 
 int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len)
@@ -609,6 +856,10 @@ int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *
     uint8_t *d_in = static_cast<uint8_t *>(ws.buf[0]);
     uint8_t *d_out = static_cast<uint8_t *>(ws.buf[1]);
     uint32_t *d_meta = static_cast<uint32_t *>(ws.buf[2]);  // [0]=src_len [1]=out_len [2]=status
+    // (large streams: the caller's buffers registered for DMA for the length of the call, as in sz_compress)
+    const bool large = ulen >= kPipelineMinBytes;
+    HostPin pin_src(large ? src : nullptr, n, true), pin_dst(large ? dst : nullptr, ulen, false);
+    SyncOnExit drain{ws};
     SZ_HIP(hipMemcpyAsync(d_in, src, n, hipMemcpyHostToDevice, ws.stream));
 
     // A stream of more than a few fragments: find the fragments' compressed offsets in parallel
@@ -625,17 +876,62 @@ int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *
         if ((rc = ws.reserve(3, work)))
             return rc;
         int32_t *d_st = reinterpret_cast<int32_t *>(d_meta);  // 3 words
-        if ((rc = sz_uncompress_stream_hip(d_in, n, body, ulen, d_out, ws.buf[3], work, d_st, ws.stream)))
-            return rc;
-        int32_t st3[3] = {1, 1, 1};
-        SZ_HIP(hipMemcpyAsync(st3, d_st, sizeof(st3), hipMemcpyDeviceToHost, ws.stream));
-        SZ_HIP(hipStreamSynchronize(ws.stream));
-        const bool good = st3[0] == 0 && st3[1] == 0 && st3[2] == 0;
-        if (good) {
-            SZ_HIP(hipMemcpyAsync(dst, d_out, ulen, hipMemcpyDeviceToHost, ws.stream));
+        if (!large) {
+            if ((rc = sz_uncompress_stream_hip(d_in, n, body, ulen, d_out, ws.buf[3], work, d_st, ws.stream)))
+                return rc;
+            int32_t st3[3] = {1, 1, 1};
+            SZ_HIP(hipMemcpyAsync(st3, d_st, sizeof(st3), hipMemcpyDeviceToHost, ws.stream));
             SZ_HIP(hipStreamSynchronize(ws.stream));
-            *out_len = ulen;
-            return SZ_OK;
+            const bool good = st3[0] == 0 && st3[1] == 0 && st3[2] == 0;
+            if (good) {
+                SZ_HIP(hipMemcpyAsync(dst, d_out, ulen, hipMemcpyDeviceToHost, ws.stream));
+                SZ_HIP(hipStreamSynchronize(ws.stream));
+                *out_len = ulen;
+                return SZ_OK;
+            }
+        } else {
+            // The whole stream has to be on the device before its fragments can be found (the index reads all of it);
+            // behind the index the fragments are decoded in stages of 4 096 and every stage's 256 MiB leave for `dst`
+            // (s_out) under the decoding of the next one.  `dst` may have been written in part when the stream turns
+            // out to be bad -- as with snappy::RawUncompress, which writes while it parses.
+            const size_t stage_frags = 4096;
+            const size_t K = (n_frag + stage_frags - 1) / stage_frags;
+            if ((rc = ws.ensure_pipeline(K + 2)))
+                return rc;
+            uint8_t *w = static_cast<uint8_t *>(ws.buf[3]);
+            const size_t idx_bytes = (szk::stream_index_scratch_bytes(n) + 15) & ~(size_t)15;  // (the layout of sz_uncompress_stream_hip's work area)
+            uint64_t *d_off = reinterpret_cast<uint64_t *>(w + idx_bytes);
+            uint32_t *d_flen = reinterpret_cast<uint32_t *>(d_off + n_frag + 1);
+            int32_t *d_fst = reinterpret_cast<int32_t *>(d_flen + n_frag);
+            uint32_t *d_res = reinterpret_cast<uint32_t *>(d_st);
+            volatile int32_t *h_st = reinterpret_cast<volatile int32_t *>(ws.pin_tot);  // pinned: [0..2] after the index, [4..6] at the end
+            SZ_HIP(szk::launch_stream_index(d_in, n, (uint32_t)body, ulen, w, d_off, d_res, ws.stream));
+            SZ_HIP(hipMemcpyAsync(const_cast<int32_t *>(h_st), d_st, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ws.stream));
+            SZ_HIP(hipEventRecord(ws.ev[K], ws.stream));
+            SZ_HIP(hipEventSynchronize(ws.ev[K]));
+            if (h_st[0] == 0 && h_st[1] == 0) {
+                for (size_t k = 0; k < K; k++) {
+                    const size_t f0 = k * stage_frags, nf = n_frag - f0 < stage_frags ? n_frag - f0 : stage_frags;
+                    const uint64_t sub = ulen - f0 * SZ_BLOCK_SIZE < nf * (uint64_t)SZ_BLOCK_SIZE ? ulen - f0 * SZ_BLOCK_SIZE : nf * (uint64_t)SZ_BLOCK_SIZE;
+                    SZ_HIP(szk::launch_uncompress_packed(d_in, d_off + f0, (uint32_t)nf, sub, d_out + f0 * SZ_BLOCK_SIZE, d_flen + f0,
+                                                         d_fst + f0, ws.stream));
+                    SZ_HIP(hipEventRecord(ws.ev[k], ws.stream));
+                }
+                SZ_HIP(szk::launch_count_failed(d_fst, (uint32_t)n_frag, d_res, ws.stream));
+                SZ_HIP(hipMemcpyAsync(const_cast<int32_t *>(h_st) + 4, d_st, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ws.stream));
+                SZ_HIP(hipEventRecord(ws.ev[K + 1], ws.stream));
+                for (size_t k = 0; k < K; k++) {
+                    const size_t o = k * stage_frags * SZ_BLOCK_SIZE, bytes = ulen - o < stage_frags * SZ_BLOCK_SIZE ? ulen - o : stage_frags * SZ_BLOCK_SIZE;
+                    SZ_HIP(hipStreamWaitEvent(ws.s_out, ws.ev[k], 0));
+                    SZ_HIP(hipMemcpyAsync(static_cast<uint8_t *>(dst) + o, d_out + o, bytes, hipMemcpyDeviceToHost, ws.s_out));
+                }
+                SZ_HIP(hipEventSynchronize(ws.ev[K + 1]));
+                SZ_HIP(hipStreamSynchronize(ws.s_out));
+                if (h_st[4] == 0 && h_st[5] == 0 && h_st[6] == 0) {
+                    *out_len = ulen;
+                    return SZ_OK;
+                }
+            }
         }
     }
     uint32_t meta[3] = {(uint32_t)n, 0, 0};

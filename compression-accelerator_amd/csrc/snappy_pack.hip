@@ -7,15 +7,22 @@ namespace szk {
 // ---------------------------------------------------------------------- stream packing (8f-2)
 
 // Exclusive prefix sum of n lengths (+base) by one 1024-thread workgroup.
+// `base_from` (may be null): the base is read from device memory instead -- the total of the chunk before this one
+// (its off[n]), so that the chunks of one stream are packed one behind the other without the host in between
+// (sz_compress's pipeline).  A base of UINT64_MAX (that chunk held an error marker) poisons this chunk too: every
+// offset becomes UINT64_MAX, which the gather below skips.
 __global__ __launch_bounds__(1024) void scan_lengths_kernel(const uint32_t *__restrict__ len, uint32_t n,
-                                                            uint64_t base, uint64_t max_len,
-                                                            uint64_t *__restrict__ off)
+                                                            uint64_t base, const uint64_t *__restrict__ base_from,
+                                                            uint64_t max_len, uint64_t *__restrict__ off)
 {
     __shared__ uint64_t part[1024];
     __shared__ uint32_t bad;
     const uint32_t t = threadIdx.x;
     if (t == 0)
         bad = 0;
+    if (base_from)
+        base = *base_from;
+    const bool poisoned = base == ~0ull;
     __syncthreads();
     const uint32_t per = (n + 1023) / 1024;
     const uint32_t lo = t * per < n ? t * per : n;
@@ -42,11 +49,11 @@ __global__ __launch_bounds__(1024) void scan_lengths_kernel(const uint32_t *__re
     uint64_t run = base + (t ? part[t - 1] : 0);
     for (uint32_t i = lo; i < hi; i++) {
         const uint32_t v = len[i];
-        off[i] = run;
+        off[i] = poisoned ? ~0ull : run;
         run += v > max_len ? 0u : v;
     }
     if (t == 1023)
-        off[n] = bad ? ~0ull : base + part[1023];
+        off[n] = (bad || poisoned) ? ~0ull : base + part[1023];
 }
 
 __global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__restrict__ slots,
@@ -57,9 +64,10 @@ __global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__rest
 {
     const uint32_t b = blockIdx.x, t = threadIdx.x;
     const uint8_t *s = slots + (uint64_t)b * slot_stride;
-    uint8_t *d = packed + off[b];
+    const uint64_t o = off[b];
+    uint8_t *d = packed + o;
     uint32_t n = len[b];
-    if (n > slot_stride)  // error marker: nothing to move (the scan reports it)
+    if (n > slot_stride || o == ~0ull)  // error marker (here, or in a chunk before this one): nothing to move (the scan reports it)
         return;
     uint32_t head = (16u - (uint32_t)((uintptr_t)d & 15u)) & 15u;
     if (head > n)
@@ -79,9 +87,9 @@ __global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__rest
 
 hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const uint32_t *d_len,
                               uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
-                              hipStream_t stream)
+                              hipStream_t stream, const uint64_t *d_base_from)
 {
-    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, stream, d_len, n_blocks, base, slot_stride, d_off);
+    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, stream, d_len, n_blocks, base, d_base_from, slot_stride, d_off);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || n_blocks == 0)
         return e;

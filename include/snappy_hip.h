@@ -47,6 +47,8 @@
  *              one parses the next window while the other moves this one's bytes).  Unset: `pair` for launches
  *              of up to 4 096 streams, `single` above.  Same output either way.
  *   SZ_SERIAL_UNCOMPRESS=1  makes sz_uncompress skip the parallel fragment index (single-wavefront decode).
+ *   SZ_NO_HOST_REGISTER=1   sz_compress / sz_uncompress on large buffers do not register the caller's memory for DMA
+ *                           (the runtime's pageable copies instead: same bytes, slower).
  *   SZ_TEST_SEG_SHIFT       a hook of the test-suite (segment size of the fragment index).
  *   SZ_DEBUG_FLAGS          only read by diagnostic builds (-DSZ_ABLATION: timing ablations with wrong output).
  */
@@ -60,7 +62,7 @@
 extern "C" {
 #endif
 
-/* The library is built with -fvisibility=hidden: the 23 functions declared here are everything it exports. */
+/* The library is built with -fvisibility=hidden: the 25 functions declared here are everything it exports. */
 #if defined(__GNUC__) || defined(__clang__)
 #define SZ_API __attribute__((visibility("default")))
 #else
@@ -188,13 +190,35 @@ SZ_API int sz_uncompress_stream_hip(const void *d_src, size_t n, size_t body, ui
 /* ---- host-buffer convenience API (what the snappy:: facade and the RoCC surface call) ---- */
 
 /* Exactly the bytes of snappy::Compress(src, n): varint32(n) + bodies of consecutive 64 KiB
- * fragments, all fragments compressed on the GPU in one launch.  n < 2^32. */
+ * fragments.  n < 2^32.  Up to 128 MiB: one copy in, one launch over all fragments, one copy out.  Larger inputs run
+ * as a pipeline of 64..256 MiB stages on three streams -- copy in of stage k+1 | fragments of stage k compressed and
+ * packed behind stage k-1's bytes | copy out of stage k-1 straight to its final place in `dst` --, with the caller's
+ * two buffers registered for DMA for the length of the call (hipHostRegister; if that fails -- or SZ_NO_HOST_REGISTER
+ * is set -- the runtime's pageable copies are used: same bytes, no overlap of the two directions).  One
+ * synchronisation at the end.  2 GiB on MI355X, PCIe included: 45 GB/s on incompressible data and on text (round 5,
+ * unpipelined: 15 / 9). */
 SZ_API int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len);
 
+/* sz_compress in two halves, for a caller that has something to do between them that needs no result yet --
+ * snappy::Compress(const char*, size_t, std::string*) has: making room in the string, std::string::resize
+ * (MaxCompressedLength), is a memset on the CPU of up to n + n/6 bytes (include/snappy/snappy.h).
+ *   sz_compress_begin   starts the call: everything that does not need `dst` is enqueued (copies in, kernels) and the
+ *                       function returns at once (0.3 ms for 2 GiB).  `src` must stay valid and unchanged until the
+ *                       matching finish.  One call in flight per host thread: a second begin returns SZ_EINVAL.
+ *   sz_compress_finish  completes it into `dst` (the copies out start while later stages still compress); same results
+ *                       and errors as sz_compress.  sz_compress_finish(NULL, 0, NULL) abandons the call.  Whatever it
+ *                       returns, nothing of the call is in flight afterwards and `src` is the caller's again.
+ * sz_compress(src, n, dst, cap, &len) == sz_compress_begin(src, n) followed by sz_compress_finish(dst, cap, &len). */
+SZ_API int sz_compress_begin(const void *src, size_t n);
+SZ_API int sz_compress_finish(void *dst, size_t dst_cap, size_t *out_len);
+
 /* snappy::Uncompress on the GPU.  *out_len receives the decoded size.  A stream of four or more
- * 64 KiB fragments is indexed in parallel on the GPU (where does each fragment begin) and decoded
- * one wavefront per fragment; shorter streams, and streams that were not written fragment by
- * fragment, are decoded by a single wavefront. */
+ * 64 KiB fragments (and fewer than 2^31 bytes) is indexed in parallel on the GPU (where does each fragment begin) and
+ * decoded one wavefront per fragment; shorter streams, and streams that were not written fragment by
+ * fragment, are decoded by a single wavefront.  From 128 MiB of output on, the caller's buffers are registered for
+ * DMA for the length of the call and the fragments are decoded in stages of 256 MiB, each copied out under the
+ * decoding of the next (2 GiB of text: 37 GB/s of output, PCIe included); `dst` may then have been written in part
+ * when the call reports a malformed stream. */
 SZ_API int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *out_len);
 
 /* snappy::GetUncompressedLength (host-side varint parse, no GPU needed). */

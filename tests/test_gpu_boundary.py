@@ -57,6 +57,91 @@ def test_host_compress_is_snappy_compress(mode, monkeypatch):
 
 
 
+@pytest.mark.timeout(300, method="thread")
+@pytest.mark.parametrize("register", ["registered", "pageable", "read_only_mapping"])
+def test_host_compress_pipeline_of_large_buffers(register, monkeypatch, tmp_path):
+    """sz_compress on a buffer of 128 MiB or more runs as a pipeline of stages (copy in | compress + pack | copy out, three
+    streams, the caller's memory registered for DMA for the length of the call): three stages with a ragged last one,
+    text, incompressible and low-entropy data side by side, bytes == the oracle's snappy::Compress.  The same without
+    registration (SZ_NO_HOST_REGISTER: the runtime's pageable copies), from a read-only file mapping (registration
+    of PROT_READ pages fails or needs the read-only flag), with a `dst` that is too small (SZ_ENOSPC, and the next call
+    is unharmed), and back through sz_uncompress."""
+    import mmap
+    if register == "pageable":
+        monkeypatch.setenv("SZ_NO_HOST_REGISTER", "1")
+    P = pkg()
+    L = P.lib()
+    mtg, rnd = fuzzgen.corpus("mtg"), fuzzgen.corpus("random_ascii")
+    n = (200 << 20) + 12345
+    parts = [(mtg * 30)[777:777 + (70 << 20)], (rnd * 600)[5:5 + (50 << 20)], (mtg[:4096] * 16) * 256]
+    parts.append((mtg * 30)[100001:100001 + n - sum(len(p) for p in parts)])
+    data = b"".join(parts)
+    assert len(data) == n
+    want = oracle_lib.raw_compress(data)
+    if register == "read_only_mapping":
+        path = tmp_path / "in.bin"
+        path.write_bytes(data)
+        f = open(path, "rb")
+        m = mmap.mmap(f.fileno(), 0, prot=mmap.PROT_READ)
+        src_holder = np.frombuffer(m, dtype=np.uint8)
+    else:
+        src_holder = np.frombuffer(data, dtype=np.uint8)
+    cap = P.max_compressed_length(n)
+    dst = np.empty(cap + 64, dtype=np.uint8)
+    dst[cap:] = 0xA5
+    got = ctypes.c_size_t(0)
+    rc = L.sz_compress(src_holder.ctypes.data, n, dst.ctypes.data, cap, ctypes.byref(got))
+    assert rc == 0 and got.value == len(want)
+    assert dst[:got.value].tobytes() == want, "pipelined sz_compress differs from the oracle"
+    assert (dst[cap:] == 0xA5).all()
+    # a destination that holds the first stage's output but not the whole stream
+    small = np.empty(len(want) - 1000 + 64, dtype=np.uint8)
+    small[-64:] = 0x5A
+    rc = L.sz_compress(src_holder.ctypes.data, n, small.ctypes.data, len(want) - 1000, ctypes.byref(got))
+    assert rc == P.SZ_ENOSPC
+    assert (small[-64:] == 0x5A).all()
+    # ... leaves nothing behind: the same call again with room, and the way back
+    rc = L.sz_compress(src_holder.ctypes.data, n, dst.ctypes.data, cap, ctypes.byref(got))
+    assert rc == 0 and dst[:got.value].tobytes() == want
+    back = np.empty(n, dtype=np.uint8)
+    rc = L.sz_uncompress(dst.ctypes.data, got.value, back.ctypes.data, n, ctypes.byref(got))
+    assert rc == 0 and got.value == n and back.tobytes() == data
+
+
+def test_compress_begin_finish_protocol():
+    """sz_compress in two halves (what snappy::Compress(..., std::string*) does around its resize): one call in flight per
+    host thread, finish without begin refused, an abandoned call leaves the thread free, and every size class --
+    nothing, one fragment, several fragments -- gives the bytes of sz_compress."""
+    P = pkg()
+    L = P.lib()
+    mtg = fuzzgen.corpus("mtg")
+    got = ctypes.c_size_t(0)
+    out = ctypes.create_string_buffer(P.max_compressed_length(400000))
+    assert L.sz_compress_finish(out, len(out), ctypes.byref(got)) == P.SZ_EINVAL  # nothing begun
+    for n in (0, 1, 130, 65536, 65537, 400000):
+        data = mtg[:n]
+        src = ctypes.create_string_buffer(data, max(1, n))
+        assert L.sz_compress_begin(src, n) == 0
+        assert L.sz_compress_begin(src, n) == P.SZ_EINVAL  # a call is in flight on this thread
+        assert L.sz_compress(src, n, out, len(out), ctypes.byref(got)) == P.SZ_EINVAL
+        assert L.sz_compress_finish(out, len(out), ctypes.byref(got)) == 0
+        assert out.raw[:got.value] == oracle_lib.raw_compress(data), n
+        assert L.sz_compress_finish(out, len(out), ctypes.byref(got)) == P.SZ_EINVAL  # finished already
+        # abandoned, then a destination that is too small: the thread is free again each time
+        assert L.sz_compress_begin(src, n) == 0
+        assert L.sz_compress_finish(None, 0, None) == 0
+        assert L.sz_compress_begin(src, n) == 0
+        assert L.sz_compress_finish(out, 0, ctypes.byref(got)) == P.SZ_ENOSPC
+        assert L.sz_compress(src, n, out, len(out), ctypes.byref(got)) == 0
+        assert out.raw[:got.value] == oracle_lib.raw_compress(data)
+    # a call begun and never finished is drained by sz_release_thread_resources
+    src = ctypes.create_string_buffer(mtg[:300000], 300000)
+    assert L.sz_compress_begin(src, 300000) == 0
+    L.sz_release_thread_resources()
+    assert L.sz_compress(src, 300000, out, len(out), ctypes.byref(got)) == 0
+    assert out.raw[:got.value] == oracle_lib.raw_compress(mtg[:300000])
+
+
 def test_host_api_one_fragment_size_sweep():
     """a single fragment goes through the small-block kernel (n <= 8 192, one block of in_stride = n) or the
     single kernel (larger; the slot is sized to its bound and the length / status words lie right behind it): every
