@@ -32,24 +32,17 @@ namespace szk {
 #define UNIFORM_JOIN() asm volatile("")
 
 // KiB of each string one step of a long match extension keeps in flight (match_length)
-#ifndef SZ_LDS_WAVE_PRIO
-#define SZ_LDS_WAVE_PRIO 3
-#endif
-#ifndef SZ_MATCH_PIECES
-#define SZ_MATCH_PIECES 4
-#endif
+static constexpr int kLdsWavePrio = 3;
+static constexpr int kMatchPiecesDefault = 4;
 
 #include "diag.h"  // MARK / TRACE / PROF_* / PE_*: nothing in the product build
 
 static constexpr uint32_t kHashMul = 0x1e35a7bdu;  // HashTable.scala:51-53, Snappy HashBytes
 static constexpr uint32_t kMaxTable = 16384u;
 static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:76-78
-#ifndef SZ_REVISIT_REGS
-#define SZ_REVISIT_REGS 1  // a second visit's new candidates' strings out of the register buffer (0: from memory, rounds 2-4)
-#endif
-#ifndef SZ_SPEC_MODE
-#define SZ_SPEC_MODE 0  // head of the next tile issued ahead of the walk: 0 never (measured best), 1 waves with the table in LDS, 2 all, 3 waves with the table in global memory with the staleness worked out in registers (round 5: -15 %)
-#endif
+// (Variants that were measured and lost live as patches under tools/patches/: heads of the next tile issued ahead of the
+// walk -- SZ_SPEC_MODE 1..3, rounds 2 and 5 -- and a second visit's candidates re-read from memory -- SZ_REVISIT_REGS=0,
+// rounds 2-4 --: spec_heads_and_revisit_from_memory.patch; EXPERIMENTS.md R5.4.)
 static constexpr uint32_t kFastMargin = 128u;  // the fast dense path stays this far from the last probe position
 
 // Probe schedule of the scan loop after a (re)start: off[k] = distance of the k-th probe from the
@@ -372,9 +365,7 @@ __device__ __forceinline__ uint32_t sel6(uint32_t r0, uint32_t r1, uint32_t r2, 
 // NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
 // loads/stores with a vmcnt(0) wait after each.  The places that need "really re-read memory"
 // (other lanes of the same store may have won the bucket) use a compiler barrier.
-#ifndef SZ_GLOB_BM_LOG2
-#define SZ_GLOB_BM_LOG2 13  // bits of the bucket number that index a global-table wave's scratch bitmap
-#endif
+static constexpr int kGlobBmLog2 = 13;  // bits of the bucket number that index a global-table wave's scratch bitmap
 template <bool in_lds>
 struct HashTab {
     uint16_t *lds;
@@ -430,9 +421,9 @@ struct HashTab {
     }
     // global home: the scratch bitmap's word and bit of bucket h (13 of its 14 bits: two buckets share a bit, and a
     // lane that finds its bit set by the other bucket is told apart by the full hashes where the cut is worked out)
-    __device__ __forceinline__ uint32_t *bm_word(uint32_t h) const { return bm + ((h & ((1u << SZ_GLOB_BM_LOG2) - 1u)) >> 5); }
+    __device__ __forceinline__ uint32_t *bm_word(uint32_t h) const { return bm + ((h & ((1u << kGlobBmLog2) - 1u)) >> 5); }
 };
-static constexpr uint32_t kGlobBmWords = (1u << SZ_GLOB_BM_LOG2) / 32u;  // scratch bitmap of a global-table wave: 8192 bits
+static constexpr uint32_t kGlobBmWords = (1u << kGlobBmLog2) / 32u;  // scratch bitmap of a global-table wave: 8192 bits
 static constexpr uint32_t kGlobOccWords = 512;  // occupancy bitmap: 16384 bits
 static constexpr uint32_t kGlobLdsWords = kGlobBmWords + kGlobOccWords;  // per global-table wave: 3 KiB of LDS
 
@@ -468,21 +459,11 @@ static constexpr uint32_t kTeamLost = 0xfffffffbu;    // return value of a wave 
 #ifndef SZ_TEAM_SPIN_CAP
 #define SZ_TEAM_SPIN_CAP (1u << 24)  // polls before a waiting wave gives the block up (seconds: only a lost wave gets there)
 #endif
-#ifndef SZ_TEAM_BASE_PRIO
-#define SZ_TEAM_BASE_PRIO 2  // issue priority of a team's waves off the token's path (the lone waves of a workgroup have 0; round 5: 2 / 3 against 1 / 2: low-entropy +2.7 %, text and mix +0.4 %)
-#endif
-#ifndef SZ_TEAM_POLL_SLEEP
-#define SZ_TEAM_POLL_SLEEP 3  // s_sleep units (64 clocks) between two polls of a token
-#endif
-#ifndef SZ_TEAM_PRIO
-#define SZ_TEAM_PRIO 3  // issue priority of the wave that holds the parse token
-#endif
-#ifndef SZ_TEAM_POLL_BACKOFF_MULT
-#define SZ_TEAM_POLL_BACKOFF_MULT 4
-#endif
-#ifndef SZ_TEAM_POLL_BACKOFF
-#define SZ_TEAM_POLL_BACKOFF 8  // polls after which a waiting wave polls four times less often (0: never)
-#endif
+static constexpr int kTeamBasePrio = 2;  // issue priority of a team's waves off the token's path (the lone waves of a workgroup have 0; round 5: 2 / 3 against 1 / 2: low-entropy +2.7 %, text and mix +0.4 %)
+static constexpr int kTeamPollSleep = 3;  // s_sleep units (64 clocks) between two polls of a token
+static constexpr int kTeamTokenPrio = 3;  // issue priority of the wave that holds the parse token
+static constexpr int kTeamPollBackoffMult = 4;
+static constexpr int kTeamPollBackoff = 8;  // polls after which a waiting wave polls four times less often (0: never)
 
 __device__ __forceinline__ uint64_t team_pack_parse(uint32_t turn, uint32_t P2, uint32_t chain2, uint32_t sc2,
                                                     uint32_t pm1, uint32_t next_emit)
@@ -496,9 +477,7 @@ __device__ __forceinline__ void team_publish(uint64_t *slot, uint64_t v)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifndef SZ_TEAM_NO_WAKEUP
     asm volatile("s_wakeup" ::: "memory");
-#endif
 }
 // Barrier among the kWaves waves of a team (s_barrier would wait for every wave of the workgroup, and the hybrid
 // kernel's workgroups hold waves that compress other blocks): a counter of arrivals that only grows; a wave waits
@@ -551,15 +530,13 @@ __device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t tur
             lost = 1;
             break;
         }
-#if SZ_TEAM_POLL_BACKOFF
         // (a wave that has polled in vain a few times is waiting for something long -- the holder follows a long
         // match, or runs the general code --: it polls four times less often from then on, its issue slots are the
         // other waves')
-        if (spin > SZ_TEAM_POLL_BACKOFF)
-            __builtin_amdgcn_s_sleep(SZ_TEAM_POLL_BACKOFF_MULT * SZ_TEAM_POLL_SLEEP);
+        if (spin > (uint32_t)kTeamPollBackoff)
+            __builtin_amdgcn_s_sleep(kTeamPollBackoffMult * kTeamPollSleep);
         else
-#endif
-        __builtin_amdgcn_s_sleep(SZ_TEAM_POLL_SLEEP);
+            __builtin_amdgcn_s_sleep(kTeamPollSleep);
     }
     asm volatile("" ::: "memory");  // nothing of what follows is read before the token
     return v;
@@ -570,7 +547,7 @@ __device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t tur
 // a sample found incompressible is built without it: its presence alone costs that instance 2 % (register
 // allocation of the strided path), and such blocks do not use it.
 template <int kBlkChunks, bool kLean, typename Tab, bool kFast = true,
-          int kMatchPieces = SZ_MATCH_PIECES, typename TeamT = NoTeam>
+          int kMatchPieces = kMatchPiecesDefault, typename TeamT = NoTeam>
 __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uint8_t *__restrict__ in,
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
                                                        uint32_t lane, const TeamT &team = TeamT{})
@@ -993,8 +970,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                             holder = true;
                         }
                         TRACE(1); MARK("T1");
-                        if (SZ_TEAM_PRIO)
-                            __builtin_amdgcn_s_setprio(SZ_TEAM_PRIO);
+                        if (kTeamTokenPrio)
+                            __builtin_amdgcn_s_setprio(kTeamTokenPrio);
                         // ---- enter the tile of P2
                         const uint32_t t2 = P2 >> 6, e2 = P2 & 63u;
                         if (__builtin_expect(((have_head ^ 1u) | (t2 ^ t)) != 0, 0)) {  // not the tile this wave has a head of: make it now
@@ -1203,8 +1180,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         const bool cont = stop == 0;
                         if (cont)
                             team_publish(team.ptok, team_pack_parse(myturn + 1, P2, chain2, sc2, pm1_done, next_emit));
-                        if (SZ_TEAM_PRIO)
-                            __builtin_amdgcn_s_setprio(SZ_TEAM_BASE_PRIO);
+                        if (kTeamTokenPrio)
+                            __builtin_amdgcn_s_setprio(kTeamBasePrio);
                         TRACE(6); MARK("T6");
                         // ---- element writer of this tile: where do its elements begin?
                         if (!own_op) {
@@ -1292,7 +1269,6 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     continue;
                 }
             }
-#ifndef SZ_NO_FAST
             if (kFast && kTeamW == 1 && chain && !hold_fast && P + kFastMargin <= ip_limit) {
                 // =================================================== FAST DENSE PATH (fixed tiles)
                 // Compressible data spends its time here.  The block is cut into fixed tiles of 64
@@ -1304,19 +1280,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 // one (lim = cut); the same tile is then visited again from there, and only the lanes
                 // whose bucket was written in between get a new candidate.  The elements of a tile are
                 // written once, when the parse leaves it (masks of all its visits accumulated).
-                // With kSpec the HEAD of tile t+1 (bytes, hashes, table lookups, candidate loads) is
-                // issued BEFORE tile t is walked: its lookups are speculative (tile t's inserts are not in
-                // the table yet) and are checked against the table once tile t has committed -- lanes
-                // whose bucket was written get the new candidate, the others' candidate bytes have long
-                // arrived.  States this path does not take (a scan that may reach probe 32, the last ~128
+                // States this path does not take (a scan that may reach probe 32, the last ~128
                 // bytes of the block) go back to the general code with (P, chain, sc, next_emit) as they
                 // stand.  tests/tile_model.py states the same algebra in plain integers (checked on the CPU).
-                // (SZ_SPEC_MODE 3, round 5: the waves whose table is in GLOBAL memory only, and what tile t has written
-                // since the look-ups of tile t+1 is worked out in registers -- the inserted lanes' hashes against the new
-                // tile's -- instead of by a second look-up: a wave with its table in memory spends most of a tile waiting
-                // for two dependent round trips, look-up then candidate strings, and both now travel under the tile before)
-                constexpr bool kSpec = SZ_SPEC_MODE == 2 || (SZ_SPEC_MODE == 1 && Tab::kInLds) || (SZ_SPEC_MODE == 3 && !Tab::kInLds);
-                constexpr bool kSpecInReg = SZ_SPEC_MODE == 3 && !Tab::kInLds;
                 first_scan = false;
                 // current tile: first dword of each position, hash, candidate (as validated), match
                 // length for the walk (4..31, or 64: reaches 32 bytes and goes on), lanes whose candidate matches
@@ -1327,10 +1293,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 // head of a tile whose candidate loads are in flight
                 u32x4 na = {0, 0, 0, 0}, na2 = {0, 0, 0, 0}, nc = {0, 0, 0, 0}, nc2 = {0, 0, 0, 0};
                 uint32_t nh = 0, ncand = 0, tn = 0;
-                bool have_spec = false;
                 // visits of the current tile accumulated for the element writer
                 uint64_t Vacc = 0, Hpacc = 0;
-                uint64_t Cacc = 0;  // (kSpecInReg) lanes of the current tile that have been inserted
                 bool acc_open = false;
                 uint32_t acc_emit = next_emit;
                 uint32_t carry = 0;  // lane j: byte acc_emit + j of an open literal that began in the tile before
@@ -1363,28 +1327,6 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     nc = ld128(in + ncand);  // ncand < pos, pos + 32 <= n here
                     nc2 = ld128(in + ncand + 16);
                 };
-                // candidates changed for the lanes in `sel` (their bucket was written after their lookup):
-                // both strings again, hit bit and match length merged in
-                auto patch = [&](uint64_t sel, uint32_t cnow, bool own_in_regs = false) {
-                    const bool on = __builtin_amdgcn_inverse_ballot_w64(sel);
-                    const uint32_t pos = (t << 6) + lane;
-                    bool hit = false;
-                    if (on) {  // (everything inside: nothing to initialise for the other lanes)
-                        tcand = cnow;
-                        u32x4 x = na, x2 = na2;  // the lanes' own bytes: still those of the head unless a next head was issued
-                        if (kSpec && !own_in_regs) {
-                            x = ld128(in + pos);
-                            x2 = ld128(in + pos + 16);
-                        }
-                        const u32x4 c = ld128(in + cnow), c2 = ld128(in + cnow + 16);
-                        const uint32_t ml = matchlen32(x, x2, c, c2);
-                        tmlw = ml == 32 ? 64u : ml;
-                        hit = c.x == x.x;
-                    }
-                    UNIFORM_JOIN();
-                    Hraw = (Hraw & ~sel) | ballot64(on && hit);
-                };
-
                 // Where the parse goes from each lane, with what the exit of a visit needs to know about the last jump
                 // beside it, so that the walk's last v_readlane IS the exit state (the team path's form, round 5 here too):
                 //   X: bits 0..5 target lane (next hit at or after this lane, then past its match), bit 6 the jump leaves the
@@ -1537,40 +1479,8 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         sc = sc2;
                         break;
                     }
-                    const uint32_t t2 = P2 >> 6, e2 = P2 & 63u;
-                    uint64_t stale = 0;
-                    uint32_t cnow = 0;
-                    if (kSpec && have_spec && t2 == tn) {
-                        // the head issued ahead is this tile: check its lookups against the table
-                        if constexpr (kSpecInReg) {
-                            // ... as it must stand now: a lane whose bucket one of the lanes inserted since (Cacc: tile t's)
-                            // has written sees the LAST of them (ascending: a later lane of a bucket overrides an earlier)
-                            cnow = ncand;
-                            uint64_t m = Cacc;
-                            while (m) {
-                                const uint32_t j = ctz64(m);
-                                m &= m - 1;
-                                const uint32_t hv = lane_get(th, j);
-                                cnow = nh == hv ? (t << 6) + j : cnow;
-                            }
-                        } else {
-                            cnow = tab.get(nh);
-                        }
-                        stale = ballot64(cnow != ncand);
-                        if (chain2 && !pm1_done) {  // P-1 goes in first: the lanes of its bucket then see it
-                            // (P-1 is lane e2-1 of the new tile, or -- a copy that ended with the old tile
-                            // behind a cut or a long match -- lane 63 of the old one)
-                            const uint32_t hp = e2 >= 1 ? lane_get(nh, e2 - 1) : lane_get(th, 63);
-                            const uint64_t same = ballot64(nh == hp) & ~below63(e2);
-                            stale |= same;
-                            cnow = __builtin_amdgcn_inverse_ballot_w64(same) ? P2 - 1 : cnow;
-                            if (lane == 0)
-                                tab.put(hp, P2 - 1);
-                            UNIFORM_JOIN();
-                        }
-                    } else {
-                        enter_head(P2, e2);
-                    }
+                    const uint32_t e2 = P2 & 63u;
+                    enter_head(P2, e2);
                     PROF_LAP(20);
                     MARK("compare");
                     {  // the head becomes the current tile: compare -> hit mask, match lengths
@@ -1585,12 +1495,9 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         t = tn;
                     }
                     PROF_LAPV(22);
-                    if (stale)
-                        patch(stale, cnow, true);
                     PROF_LAPV(24);
                     Vacc = 0;
                     Hpacc = 0;
-                    Cacc = 0;
                     acc_open = chain2 == 0;
                     acc_emit = next_emit;
                     e = e2;
@@ -1598,13 +1505,6 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     sc_in = sc2;
                     const uint32_t base = t << 6;
                     const uint32_t pos = base + lane;
-                    // ---- (C) head of the next tile, ahead of this tile's walk (lookups checked afterwards)
-                    have_spec = kSpec && base + 64 + kFastMargin <= ip_limit;
-                    if (have_spec) {
-                        head(t + 1);
-                        ncand = tab.get(nh);
-                        head_loads();
-                    }
                     PROF_LAP(25);
                     if (kFastX)
                         jumps();
@@ -1743,8 +1643,6 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         next_emit = emit2;
                         Vacc |= V;
                         Hpacc |= Hp;
-                        if (kSpecInReg)
-                            Cacc |= C;
                         long_lane = ll;  // (64: none)
                         // (one way out of the visits of a tile: every exit of its own costs a set of copies)
                         if (__builtin_expect(poisoned | (ll < 64) | ((P2 >> 6) != t), 1))
@@ -1754,18 +1652,13 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         const uint32_t e2s = P2 & 63u;
                         if (chain2 && lane == e2s - 1)
                             tab.put(th, pos);
-                        if (kSpecInReg && chain2)
-                            Cacc |= 1ull << ((e2s - 1u) & 63u);
                         asm volatile("" ::: "memory");
                         const uint32_t cn = tab.get(th);
                         const uint64_t st = ballot64(cn != tcand) & ~below63(e2s);
                         if (st) {
                             // (what has been written since the tile's look-ups was written by this tile's own inserts: the new
                             // candidates lie in the tile, their strings in the register buffer -- no round trip to memory)
-                            if (SZ_REVISIT_REGS && !kSpec)
-                                patch_regs(st, cn);
-                            else
-                                patch(st, cn);
+                            patch_regs(st, cn);
                             jumps();
                         }
                         PROF_LAPV(23);
@@ -1780,7 +1673,6 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                 want_prep(P - (chain ? 1u : 0u), chain);
                 continue;
             }
-#endif
             if (chain || sc <= 31) {
                 // =================================================== dense window
                 if (P >= ip_limit)
@@ -2548,7 +2440,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
     // leaves the CU), so every slot they take is used; the others spend most of their time waiting
     // for their table in the L2 anyway (measured: text +2.7 %, low-entropy +2.4 %, mix unchanged).
     if (wave == 0)
-        __builtin_amdgcn_s_setprio(SZ_LDS_WAVE_PRIO);
+        __builtin_amdgcn_s_setprio(kLdsWavePrio);
     for (;;) {
         // One queue for the whole grid: faster waves take more blocks.  The counter's address goes
         // through VGPRs on purpose: experimental builds of this kernel that hung had `select` spilled
@@ -2598,11 +2490,9 @@ __global__ __launch_bounds__(64 * kGroupWaves) __attribute__((amdgpu_waves_per_e
 #ifndef SZ_TEAM_WAVES
 #define SZ_TEAM_WAVES 2  // waves of a team (2..4)
 #endif
-#ifndef SZ_LONE_WAVES
-#define SZ_LONE_WAVES 2  // global-table waves beside the team in each workgroup (0..2)
-#endif
+static constexpr int kLoneWavesDefault = 2;  // global-table waves beside the team in each workgroup (0..2)
 static constexpr int kTeamWaves = SZ_TEAM_WAVES > 1 ? SZ_TEAM_WAVES : 2;
-static constexpr int kLoneWaves = SZ_LONE_WAVES;
+static constexpr int kLoneWaves = kLoneWavesDefault;
 static constexpr int kHybridWaves = kTeamWaves + kLoneWaves;
 static constexpr int kHybridPerSimd = kHybridWaves;  // four workgroups per CU, one wave of each per SIMD
 // The team kernel's arguments as ONE struct passed by value: it lies at offset 0 of the kernel-argument segment, and
@@ -2697,7 +2587,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
     }
     const HashTab<true> tab{lds_tab, nullptr, nullptr, nullptr};
     WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr, dup_scr + wave * 256u, &team_bar};
-    __builtin_amdgcn_s_setprio(SZ_TEAM_BASE_PRIO);  // (a team's waves go before the lone ones; the token's holder before both)
+    __builtin_amdgcn_s_setprio(kTeamBasePrio);  // (a team's waves go before the lone ones; the token's holder before both)
     // Giving up (a wave of the team stalled for seconds: SZ_TEAM_SPIN_CAP): the wave that gives up raises
     // `team_dead` and every wave of the team leaves the persistent loop at its next look at it -- the barrier's
     // arrival count is not trusted again.  The block in hand is poisoned (0xfffffffe).  out_len[b] has ONE writer
@@ -2738,7 +2628,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
         TRACE_ATTACH(team, b, wave, kTeamWaves);
         const uint8_t *in_b = as_global<const uint8_t>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
         uint8_t *out_b = as_global<uint8_t>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
-        const uint32_t op = compress_one_block<0, true, HashTab<true>, true, SZ_MATCH_PIECES, WaveTeam<kTeamWaves>>(
+        const uint32_t op = compress_one_block<0, true, HashTab<true>, true, kMatchPiecesDefault, WaveTeam<kTeamWaves>>(
             tab, in_b, n, out_b, uni(a->flags), lane, team);
         if (op != kTeamNotMine) {
             // (a9) the wave that finished the block, or the first wave that gave it up: every lane, same address, same value
