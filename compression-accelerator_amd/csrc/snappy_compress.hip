@@ -2579,6 +2579,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             const HashTab<false> gtab{nullptr, my_glob, lone_bm + lw * kGlobLdsWords + kGlobOccWords, lone_bm + lw * kGlobLdsWords};
             const uint8_t *in_b = as_global<const uint8_t>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
             uint8_t *out_b = as_global<uint8_t>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
+            EXP_STARTED(b);
             const uint32_t op = compress_one_block<0, true>(gtab, in_b, n, out_b, uni(a->flags), lane);
             store_len(b, EXP_LONE_MARK(op));
             EXP_FINISHED(b);
@@ -2626,6 +2627,7 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             continue;
         }
         TRACE_ATTACH(team, b, wave, kTeamWaves);
+        EXP_STARTED(b);
         const uint8_t *in_b = as_global<const uint8_t>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
         uint8_t *out_b = as_global<uint8_t>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
         const uint32_t op = compress_one_block<0, true, HashTab<true>, true, kMatchPiecesDefault, WaveTeam<kTeamWaves>>(

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 int main(int argc, char **argv)
 {
     FILE *f = fopen(argv[1], "rb");
@@ -63,6 +64,31 @@ int main(int argc, char **argv)
             printf("\n  by lone waves:                                   ");
             for (int k = 0; k < 10; k++) printf(" %u", hist[1][k]);
             printf("\n  first to last finish: %.3f ms\n", (t1 - t0) / 1e5);
+            // the end of the launch (round 6): when was the last block taken out of the queue, how long did the blocks of
+            // each kind of worker take, and how many were still being worked on k x 0.25 ms after the queue was empty
+            std::vector<unsigned long long> sta(nb);
+            if (hipMemcpyFromSymbol(sta.data(), HIP_SYMBOL(szk::g_start), (size_t)nb * 8) != hipSuccess) return 2;
+            unsigned long long s0 = ~0ull, s1 = 0;
+            double dur[2] = {0, 0}; unsigned cnt[2] = {0, 0};
+            for (uint32_t b = 0; b < nb; b++) { if (sta[b] < s0) s0 = sta[b]; if (sta[b] > s1) s1 = sta[b]; int r = (ol[b] >> 31) ? 1 : 0; dur[r] += (double)(fin[b] - sta[b]); cnt[r]++; }
+            printf("  first block taken at 0, last block taken at %.3f ms, last block finished at %.3f ms: the launch ends %.3f ms after its queue is empty\n",
+                   (s1 - s0) / 1e5, (t1 - s0) / 1e5, (t1 - s1) / 1e5);
+            printf("  mean time per block: teams %.3f ms, lone waves %.3f ms\n", cnt[0] ? dur[0] / cnt[0] / 1e5 : 0.0, cnt[1] ? dur[1] / cnt[1] / 1e5 : 0.0);
+            printf("  blocks in work k x 0.25 ms after the queue was empty (teams / lone):");
+            for (int k = 0; k < 20; k++) {
+                unsigned long long at = s1 + (unsigned long long)k * 25000ull;
+                unsigned w[2] = {0, 0};
+                for (uint32_t b = 0; b < nb; b++) if (fin[b] > at) w[(ol[b] >> 31) ? 1 : 0]++;
+                printf(" %u/%u", w[0], w[1]);
+                if (w[0] + w[1] == 0) break;
+            }
+            // the blocks that were finished last: when were they taken?
+            printf("\n  the 8 blocks finished last (role, taken at, finished at, ms):");
+            std::vector<uint32_t> idx(nb);
+            for (uint32_t b = 0; b < nb; b++) idx[b] = b;
+            std::partial_sort(idx.begin(), idx.begin() + (nb < 8 ? nb : 8), idx.end(), [&](uint32_t x, uint32_t y) { return fin[x] > fin[y]; });
+            for (uint32_t k = 0; k < 8 && k < nb; k++) printf(" [%s %.2f %.2f]", (ol[idx[k]] >> 31) ? "lone" : "team", (sta[idx[k]] - s0) / 1e5, (fin[idx[k]] - s0) / 1e5);
+            printf("\n");
         }
     }
     return 0;
