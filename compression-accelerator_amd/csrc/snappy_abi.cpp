@@ -609,7 +609,7 @@ int sz_uncompress_stream_hip(const void *d_src, size_t n, size_t body, uint64_t 
                              size_t work_bytes, int32_t *d_status3, void *stream)
 {
     if (!d_src || !d_dst || !d_work || !d_status3 || n == 0 || body == 0 || body > 5 || body > n ||
-        n > 0x7fffffffull || ulen == 0 || ulen > 0xffffffffull)
+        n > SZ_STREAM_INDEX_MAX_BYTES || ulen == 0 || ulen > 0xffffffffull)
         return SZ_EINVAL;
     if (work_bytes < sz_uncompress_stream_work_bytes(n, ulen))
         return SZ_ENOSPC;
@@ -867,7 +867,7 @@ int sz_uncompress(const void *src, size_t n, void *dst, size_t dst_cap, size_t *
     // that was not produced in 64 KiB fragments, a malformed element -- falls through to the serial
     // decoder below, which also produces the error code.
     const size_t n_frag = (ulen + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE;
-    if (n_frag >= 4 && n <= 0x7fffffffull && !getenv("SZ_SERIAL_UNCOMPRESS")) {
+    if (n_frag >= 4 && n <= SZ_STREAM_INDEX_MAX_BYTES && !getenv("SZ_SERIAL_UNCOMPRESS")) {
         size_t body = 0;
         while (body < 5 && (static_cast<const uint8_t *>(src)[body] & 0x80))
             body++;

@@ -980,7 +980,8 @@ size_t stream_index_scratch_bytes(uint64_t n)
            n_seg * (kFarSlots * sizeof(FarEntry) + sizeof(uint32_t)) + 16 + 64;  // far maps + their counters, pass 0's flag
 }
 
-// d_in: the whole raw stream (n < 2^31 bytes, readable up to n + 8), body = size of its preamble,
+// d_in: the whole raw stream (n <= SZ_STREAM_INDEX_MAX_BYTES = 2^32 - 256 KiB: positions are 32-bit, 0xffffffff is "none", and
+// seg_base + segment, p + 72 and n + 8 must not wrap; readable up to n + 8), body = size of its preamble,
 // ulen = the decoded size it announces, n_frag = ceil(ulen / 64 KiB).  Fills d_off[0 .. n_frag]
 // (boundaries that are not found stay UINT64_MAX) and d_result[0..1] = {parse status, boundary
 // flags}; d_result[2] := 0 (see launch_count_failed).

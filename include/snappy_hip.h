@@ -71,6 +71,9 @@ extern "C" {
 
 #define SZ_BLOCK_SIZE 65536u      /* Snappy fragment size: one block per wavefront */
 #define SZ_SLOT_STRIDE 76544u     /* default output slot: >= sz_max_compressed_length(65536)=76490, 128-B multiple */
+#define SZ_STREAM_INDEX_MAX_BYTES 0xfffc0000ull  /* longest raw stream sz_uncompress_stream_hip indexes: 32-bit positions with room
+                                                    for one more segment and one more element behind the last byte (round 6;
+                                                    before: 2^31 - 1, which 2 GiB of incompressible data exceed by 98 KB) */
 
 #define SZ_OK 0
 #define SZ_EINVAL (-22)
@@ -176,7 +179,7 @@ SZ_API int sz_uncompress_packed_hip(const void *d_packed, const uint64_t *d_off,
  * information: the compressed offsets of its 64 KiB fragments are found on the GPU (64 hypothetical
  * parses per 16 KiB segment, then the true one through their maps), then every fragment is decoded by
  * its own wavefront.  body = size of the varint preamble (1..5), ulen = the decoded size it
- * announces (sz_get_uncompressed_length on the first bytes), n < 2^31; d_src must be readable up to
+ * announces (sz_get_uncompressed_length on the first bytes), n <= SZ_STREAM_INDEX_MAX_BYTES; d_src must be readable up to
  * n + 8; d_dst holds ulen bytes; d_work holds sz_uncompress_stream_work_bytes(n, ulen).
  * Asynchronous.  d_status3[0..2] = {the stream does not parse, an element straddles a 64 KiB output
  * boundary, number of fragments that failed to decode}: all zero = d_dst is the decoded stream.
@@ -213,7 +216,7 @@ SZ_API int sz_compress_begin(const void *src, size_t n);
 SZ_API int sz_compress_finish(void *dst, size_t dst_cap, size_t *out_len);
 
 /* snappy::Uncompress on the GPU.  *out_len receives the decoded size.  A stream of four or more
- * 64 KiB fragments (and fewer than 2^31 bytes) is indexed in parallel on the GPU (where does each fragment begin) and
+ * 64 KiB fragments (and at most SZ_STREAM_INDEX_MAX_BYTES bytes) is indexed in parallel on the GPU (where does each fragment begin) and
  * decoded one wavefront per fragment; shorter streams, and streams that were not written fragment by
  * fragment, are decoded by a single wavefront.  From 128 MiB of output on, the caller's buffers are registered for
  * DMA for the length of the call and the fragments are decoded in stages of 256 MiB, each copied out under the

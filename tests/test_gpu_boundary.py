@@ -942,6 +942,46 @@ def test_device_stream_decode_without_side_information():
     assert st[0] == 0 and st[1] != 0
 
 
+@pytest.mark.timeout(300, method="thread")
+def test_stream_index_beyond_two_to_the_31_bytes():
+    """Round 6: the fragment index takes streams up to SZ_STREAM_INDEX_MAX_BYTES (2^32 - 256 KiB; before: 2^31 - 1, and
+    2 GiB of incompressible data compress to 2 147 582 000 bytes: sz_uncompress fell to the serial decoder, 6.7 GB/s).
+    A stream of 2.6e9 bytes -- 2 GiB of tiled randomASCII followed by 1 GiB of text, so that both the runs pass and the
+    segment maps work behind position 2^31 --, compressed and packed on the device, decoded from its bytes alone:
+    all three status words zero, output == input; and one byte beyond the limit is refused."""
+    import torch
+    sys_path_bench()
+    import bench
+    P = pkg()
+    dev = torch.device("cuda:0")
+    nb_a, nb_b = 32768, 16384
+    src = torch.cat([bench.make_input("c3", 0, nb_a, dev), bench.make_input("text", 7, nb_b, dev)])
+    n = int(src.numel())
+    nb = nb_a + nb_b
+    hdr = _varint(n)
+    slots, lens, _ = P.compress_stream(src, n)
+    packed = torch.zeros(len(hdr) + int(lens.to(torch.int64).sum().item()) + 64, dtype=torch.uint8, device=dev)
+    packed[:len(hdr)] = torch.tensor(list(hdr), dtype=torch.uint8, device=dev)
+    _, offs = P.pack_stream(slots, P.SLOT_STRIDE, lens, nb, base=len(hdr), packed=packed)
+    total = int(offs[nb].item())
+    del slots
+    assert total > (1 << 31) + (1 << 28)
+    back, st = P.uncompress_stream(packed, total, len(hdr), n)
+    torch.cuda.synchronize()
+    assert st.cpu().numpy().tolist() == [0, 0, 0]
+    assert bool(torch.equal(back, src))
+    # the limit itself is an argument error, before anything is launched
+    rc = P.lib().sz_uncompress_stream_hip(packed.data_ptr(), 0xfffc0000 + 1, len(hdr), n, back.data_ptr(), packed.data_ptr(), 1 << 40,
+                                          st.data_ptr(), None)  # (argument checks come first: nothing is launched)
+    assert rc == P.SZ_EINVAL
+
+
+def sys_path_bench():
+    import sys
+    if build_util.ROOT not in sys.path:
+        sys.path.insert(0, build_util.ROOT)
+
+
 def test_streams_of_big_elements_go_through_the_runs_pass():
     """Pass 0 of the stream index (one wave following runs of equal-sized big elements) covers a stream whose
     fragments are one literal each; a stream it cannot cover falls to the segment passes.  Either way the decode

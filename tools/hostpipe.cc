@@ -45,6 +45,19 @@ int main(int argc, char **argv)
     std::vector<char> in(n), out(bound(n)), back(n);
     for (size_t o = 0; o < n; o += cn)
         memcpy(in.data() + o, corpus.data(), n - o < cn ? n - o : cn);
+    if (argc > 5) {  // a second kind of data behind the first (a stream whose fragments are not all alike)
+        FILE *g = fopen(argv[5], "rb");
+        if (!g)
+            return 2;
+        fseek(g, 0, SEEK_END);
+        const size_t bn = (size_t)ftell(g);
+        fseek(g, 0, SEEK_SET);
+        std::vector<char> second(bn);
+        if (fread(second.data(), 1, bn, g) != bn)
+            return 2;
+        for (size_t o = n / 3 * 2; o < n; o += bn)
+            memcpy(in.data() + o, second.data(), n - o < bn ? n - o : bn);
+    }
     memset(out.data(), 1, out.size());
     memset(back.data(), 1, back.size());
     size_t clen = 0, ulen = 0;
