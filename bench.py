@@ -392,8 +392,12 @@ def host_api_rates(P, n_bytes, reps=3):
            "what": "sz_compress / sz_uncompress on pageable host memory, wall clock, PCIe both ways included: a pipeline of 64..256 MiB "
                    "stages (copy in | compress + pack | copy out) with the caller's buffers registered for DMA for the length of the call"}
     cap = P.max_compressed_length(n_bytes)
-    dst = np.empty(cap, dtype=np.uint8)
-    back = np.empty(n_bytes, dtype=np.uint8)
+    # (written once before the calls, as a caller's buffers are -- snappy::Compress resizes its std::string, which zero-fills
+    # it; pages that no one has touched yet are faulted in one by one under the first copy that lands on them)
+    dst = np.zeros(cap, dtype=np.uint8)
+    back = np.zeros(n_bytes, dtype=np.uint8)
+    dst[::4096] = 1
+    back[::4096] = 1
     got = ctypes.c_size_t(0)
     for kind, name in (("c3", "incompressible"), ("text", "text")):
         src = make_input(kind, 0, n_bytes // BLOCK, "cpu").numpy()
@@ -411,7 +415,8 @@ def host_api_rates(P, n_bytes, reps=3):
             tu.append(time.perf_counter() - t0)
             assert rc == 0, rc
         want = oracle_lib.raw_compress(src)
-        out[name] = {"compress_GBps": round(n_bytes / sorted(ts[1:])[len(ts[1:]) // 2] / 1e9, 2),
+        out[name] = {"compress_ms": [round(t * 1e3, 1) for t in ts], "uncompress_ms": [round(t * 1e3, 1) for t in tu],
+                     "compress_GBps": round(n_bytes / sorted(ts[1:])[len(ts[1:]) // 2] / 1e9, 2),
                      "uncompress_GBps": round(n_bytes / sorted(tu[1:])[len(tu[1:]) // 2] / 1e9, 2),
                      "first_call_ms": round(ts[0] * 1e3, 1), "stream_bytes": clen,
                      "bytes_equal_oracle": bool(clen == len(want) and dst[:clen].tobytes() == want),
