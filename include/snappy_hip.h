@@ -211,6 +211,9 @@ SZ_API int sz_compress(const void *src, size_t n, void *dst, size_t dst_cap, siz
  *   sz_compress_finish  completes it into `dst` (the copies out start while later stages still compress); same results
  *                       and errors as sz_compress.  sz_compress_finish(NULL, 0, NULL) abandons the call.  Whatever it
  *                       returns, nothing of the call is in flight afterwards and `src` is the caller's again.
+ *                       Begin and finish are calls of ONE host thread (the state between them is the thread's own, like
+ *                       the RoCC port's latched length); sz_release_thread_resources() drains and drops a call that
+ *                       was begun and never finished.
  * sz_compress(src, n, dst, cap, &len) == sz_compress_begin(src, n) followed by sz_compress_finish(dst, cap, &len). */
 SZ_API int sz_compress_begin(const void *src, size_t n);
 SZ_API int sz_compress_finish(void *dst, size_t dst_cap, size_t *out_len);
