@@ -51,6 +51,7 @@ static constexpr uint32_t kTraceCap = 16384, kTraceBlocks = 8;
 __device__ unsigned long long g_finish[1u << 18];  // (tools/rolecount.hip: s_memrealtime at which each block was finished; 100 MHz, one clock for the whole GPU)
 #define EXP_LONE_MARK(op) ((op) | 0x80000000u)  // a block done by a lone wave
 #define EXP_SINGLE_MARK(op) ((op) | 0x40000000u)  // a block done by the single kernel (tests/test_gpu_routing.py: who wrote which block)
+#define EXP_ADOPT_MARK(op) ((op) | 0x20000000u)   // a block begun by a lone wave and finished by its workgroup's team (tests/test_gpu_adoption.py)
 #define EXP_FINISHED(b) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_finish[(b) & 0x3ffffu] = t_; } while (0)  // (every lane, same address, same value)
 __device__ unsigned long long g_start[1u << 18];   // ... and at which it was taken out of the queue (round 6: the shape of a launch's end)
 #define EXP_STARTED(b) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_start[(b) & 0x3ffffu] = t_; } while (0)
@@ -58,6 +59,7 @@ __device__ unsigned long long g_start[1u << 18];   // ... and at which it was ta
 #define EXP_STARTED(b) do { } while (0)
 #define EXP_LONE_MARK(op) (op)
 #define EXP_SINGLE_MARK(op) (op)
+#define EXP_ADOPT_MARK(op) (op)
 #define EXP_FINISHED(b) do { } while (0)
 #endif
 #ifdef SZ_PROF

@@ -20,6 +20,7 @@
 // No MFMA: this is byte/integer work bounded by HBM ("Roofline").
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "wave_utils.h"
 
@@ -426,6 +427,9 @@ struct HashTab {
 static constexpr uint32_t kGlobBmWords = (1u << kGlobBmLog2) / 32u;  // scratch bitmap of a global-table wave: 8192 bits
 static constexpr uint32_t kGlobOccWords = 512;  // occupancy bitmap: 16384 bits
 static constexpr uint32_t kGlobLdsWords = kGlobBmWords + kGlobOccWords;  // per global-table wave: 3 KiB of LDS
+// (team kernel) behind them, per lone wave: the adoption request, the wave's state as its team sees it, the record handed over
+static constexpr uint32_t kLoneReqWord = kGlobLdsWords, kLoneStateWord = kGlobLdsWords + 1, kLoneRecWord = kGlobLdsWords + 2;
+static constexpr uint32_t kLoneLdsWords = kGlobLdsWords + 8;
 
 // ------------------------------------------------------------------------ wave teams
 //
@@ -452,7 +456,28 @@ struct WaveTeam {
     unsigned long long *trace;  // (-DSZ_TRACE builds: this wave's stamps for this block, or null)
     uint8_t *scr;    // LDS: 256 bytes of scratch of this wave's own (lanes that share a bucket inside a tile)
     uint32_t *bar;   // LDS: arrivals at the team's barrier (the workgroup may hold waves that are not of the team)
+    // ADOPTION (round 6; see "the end of a launch" at the team kernel; the instance with AdoptT = TeamAdopt): the block is
+    // one that a lone wave of this workgroup has handed over in mid-parse -- its parse state is in the kAdoptRec* words
+    // at `arec` (LDS), its hash table has been copied into the team's by the kernel
+    const uint32_t *arec;
 };
+// What a lone wave does about adoption inside compress_one_block: nothing (every kernel but the team kernel), or it
+// looks at `req` once per tile of the fast dense path and, asked to, hands the block over where a tile ends.
+struct NoAdopt {
+    static constexpr bool kLone = false, kResume = false;
+};
+struct TeamAdopt {  // a team goes on with a block that a lone wave has handed over
+    static constexpr bool kLone = false, kResume = true;
+};
+struct LoneAdopt {  // (the request word and the record lie behind the wave's bitmaps in LDS, at kLoneReqWord / kLoneRecWord
+                    // from `tab.occ`: no pointer of their own to keep in a register file that has none to spare)
+    static constexpr bool kLone = true, kResume = false;
+};
+static constexpr uint32_t kAdoptIdle = 0, kAdoptAsked = 1, kAdoptTaken = 2, kAdoptWithdrawn = 3;  // a request's life
+static constexpr uint32_t kLoneRunning = 0, kLoneLeft = 1, kLoneHanded = 2, kLoneAdopted = 3;     // a lone wave's state, as its team sees it
+static constexpr uint32_t kAdoptRecBlock = 0, kAdoptRecState = 1, kAdoptRecEmit = 2, kAdoptRecOp = 3;  // (words of the record, from kLoneRecWord)
+static constexpr uint32_t kAdoptMinBlock = 16384;  // blocks this long or longer are handed over (their table has all 16384 entries) ...
+static constexpr uint32_t kAdoptMinLeft = 4096;    // ... while this much of them is still to be parsed
 static constexpr uint32_t kTeamDoneTurn = 0x3fffffu;  // turn field of a token: the block is finished
 static constexpr uint32_t kTeamNotMine = 0xfffffffcu; // return value of the waves that did not finish the block
 static constexpr uint32_t kTeamLost = 0xfffffffbu;    // return value of a wave that gave up waiting for its team (never stored: the kernel poisons the block)
@@ -547,10 +572,11 @@ __device__ __forceinline__ uint64_t team_wait(const uint64_t *slot, uint32_t tur
 // a sample found incompressible is built without it: its presence alone costs that instance 2 % (register
 // allocation of the strided path), and such blocks do not use it.
 template <int kBlkChunks, bool kLean, typename Tab, bool kFast = true,
-          int kMatchPieces = kMatchPiecesDefault, typename TeamT = NoTeam>
+          int kMatchPieces = kMatchPiecesDefault, typename TeamT = NoTeam, typename AdoptT = NoAdopt>
 __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uint8_t *__restrict__ in,
                                                        uint32_t n, uint8_t *__restrict__ out, uint32_t flags,
-                                                       uint32_t lane, const TeamT &team = TeamT{})
+                                                       uint32_t lane, const TeamT &team = TeamT{},
+                                                       const AdoptT & = AdoptT{})
 {
     PE_START();
     constexpr int kTeamW = TeamT::kWaves;  // 1: this wave compresses the block alone
@@ -569,8 +595,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
     // value merged behind the per-lane `if`: the compiler keeps the whole parse state in scalar
     // registers only while it can prove it uniform -- `opt -passes='print<uniformity>'`.)
     const uint32_t nb = (flags & kFlagBlockVarint) ? (n < 128 ? 1u : (n < 16384 ? 2u : 3u)) : 0u;
+    constexpr bool adopted = AdoptT::kResume;  // team mode: the block comes from a lone wave in mid-parse (its preamble is written, its table is taken over)
+    static_assert(!adopted || kTeamW > 1, "only a team adopts");
     if constexpr (kTeamW > 1) {
-        if (holder && lane < nb)
+        if (holder && lane < nb && !adopted)
             out[lane] = (uint8_t)(((n >> (7 * lane)) & 0x7f) | (lane + 1 < nb ? 0x80 : 0));
         UNIFORM_JOIN();
     } else {
@@ -715,9 +743,11 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         const uint32_t shift = 32 - log2T;
         if constexpr (kTeamW > 1) {
             if (n >= 1024) {  // the whole team: a slice each, then every wave sees an empty table
+                if constexpr (!adopted) {  // (an adopted block: the kernel has copied its lone wave's table into this one)
                 const uint32_t nvec = (1u << log2T) >> 3;
                 for (uint32_t i = team.wave * 64u + lane; i < nvec; i += 64u * kTeamW)
                     reinterpret_cast<u32x4 *>(tab.lds)[i] = u32x4{0, 0, 0, 0};
+                }
                 // (a lost barrier: the table is not known to be clear -- the main loop is left at its first test and
                 // the wave returns kTeamLost, the kernel poisons the block)
                 team_lost = uni(team_barrier<kTeamW, false>(team.bar, nullptr, lane)) != 0;
@@ -781,6 +811,23 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
         uint32_t sc = 0;         // scan: index of the next probe
         uint32_t scan_base = 1;  // scan: position of probe 0 (skip == 32 there)
         bool first_scan = !kLean;  // pv[] belongs to the scan that starts at 1
+        if constexpr (kTeamW > 1) {
+            if constexpr (adopted) {
+                // an adopted block: the state its lone wave left the fast dense path with, exactly as that path hands a
+                // state to the general code (every wave of the team reads it; it matters to wave 0, which holds the token)
+                const uint32_t st = uni(team.arec[kAdoptRecState]);
+                P = st & 0x1ffffu;
+                chain = ((st >> 17) & 1u) != 0;
+                sc = (st >> 18) & 63u;
+                next_emit = uni(team.arec[kAdoptRecEmit]);
+                op = uni(team.arec[kAdoptRecOp]);
+                if (!chain)
+                    scan_base = P - sc;
+                prepW = P - (chain ? 1u : 0u);
+                prepC = chain;
+                first_scan = false;
+            }
+        }
         PE_LAP(29);
         PROF_DECL
         PROF_START();
@@ -1473,6 +1520,41 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                     // ---- (B) enter the tile of P2 -- or leave: the block's tail, a state handed back (quit: P2,
                     // chain2, sc2 are that state), a poisoned block (one way out: every exit of its own costs copies)
                     MARK("enter");
+                    if constexpr (AdoptT::kLone) {
+                        // (a lone wave of the team kernel) The workgroup's team has run out of blocks and asks for this one:
+                        // it is handed over here, where a tile ends -- its elements are written, (P2, chain2, sc2, next_emit,
+                        // op) is the whole parse state, as for a state handed to the general code -- if enough of it is left
+                        // to be worth a table's copy.  One LDS word read per tile; the claim is an LDS compare-and-swap (the
+                        // team may withdraw its request: exactly one side gets it).
+                        uint32_t *const req = tab.occ + kLoneReqWord, *const rec = tab.occ + kLoneRecWord;
+                        if (__builtin_expect(uni(__hip_atomic_load(req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kAdoptAsked, 0) &&
+                            ip_limit >= kAdoptMinBlock && P2 + kAdoptMinLeft <= ip_limit && quit == 0 && !poisoned) {
+                            uint32_t was = kAdoptIdle;
+                            if (lane == 0) {
+                                uint32_t expect = kAdoptAsked;
+                                (void)__hip_atomic_compare_exchange_strong(req, &expect, kAdoptTaken, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                                was = expect;
+                            }
+                            UNIFORM_JOIN();
+                            if (uni(was) == kAdoptAsked) {
+                                // everything this wave has stored -- elements, table entries -- is in the L2 before the team is
+                                // told (workgroup-scope release: the team's waves run on this CU)
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                if (lane == 0) {
+                                    rec[kAdoptRecState] = P2 | (chain2 << 17) | (sc2 << 18);
+                                    rec[kAdoptRecEmit] = next_emit;
+                                    rec[kAdoptRecOp] = op;
+                                }
+                                UNIFORM_JOIN();
+                                // (no exit of its own -- every exit of this loop costs the allocator a set of copies, measured
+                                // in rounds 3-5 --: the block leaves by the way a poisoned one does, with nothing left to emit; the
+                                // kernel tells the two apart by the request word, which reads kAdoptTaken from here on)
+                                next_emit = n;
+                                poisoned = true;
+                            }
+                        }
+                    }
                     if (__builtin_expect((quit != 0) | poisoned | (P2 + kFastMargin > ip_limit), 0)) {
                         P = P2;
                         chain = chain2 != 0;
@@ -2510,7 +2592,7 @@ struct TeamArgs {
     uint16_t *scratch_tables;
     uint32_t *select;
     const uint32_t *queue;  // routed launches: block indices, class 2 from [0], class 1 from [queue_half]
-    uint32_t n_blocks, flags, auto_mode;  // auto_mode bit 0: the launch was sampled (else: every block, by name)
+    uint32_t n_blocks, flags, auto_mode;  // auto_mode bit 0: the launch was sampled (else: every block, by name); bit 1: no adoption at the launch's end
     uint32_t queue_half;    // 0: no routing
 };
 __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_eu(kHybridPerSimd, kHybridPerSimd))) void compress_blocks_team_kernel(TeamArgs args_in_kernarg)
@@ -2518,8 +2600,18 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
     __shared__ __attribute__((aligned(16))) uint16_t lds_tab[kMaxTable];
     __shared__ __attribute__((aligned(16))) uint64_t tokens[2];
     __shared__ __attribute__((aligned(16))) uint8_t dup_scr[kTeamWaves * 256];
-    __shared__ __attribute__((aligned(16))) uint32_t lone_bm[(kLoneWaves > 0 ? kLoneWaves : 1) * kGlobLdsWords];  // per global-table wave: scratch bitmap + occupancy bitmap
+    __shared__ __attribute__((aligned(16))) uint32_t lone_bm[(kLoneWaves > 0 ? kLoneWaves : 1) * kLoneLdsWords];  // per global-table wave: occupancy bitmap + scratch bitmap + adoption words
     __shared__ uint32_t next_block, team_bar, team_dead, len_claim;
+    // THE END OF A LAUNCH (round 6).  The queue runs empty while every lone wave is inside a block that it needs
+    // ~3.8 ms for (a team: 1.75): round 5 ended a launch of text with ~2.9 ms of idle teams.  A team that finds
+    // the queue empty ADOPTS the block of a lone wave of its own workgroup: it asks (the lone wave's request word,
+    // behind its bitmaps in lone_bm), the lone wave hands the block over at the end of its tile -- parse state into its
+    // record; its table is in memory, the bitmap of the buckets it has written in this very LDS -- and leaves; the team
+    // copies the table into its own (32 KiB out of the L2) and goes on from that state at a team's pace: the same bytes by
+    // construction (the state is the one the fast dense path hands to the general code; tests/test_gpu_adoption.py).
+    // Nothing is compressed twice, a length has one writer.  The loop at the end of the kernel.
+    __shared__ uint32_t adopt_sel;
+    auto lone_word = [&](uint32_t w, uint32_t k) -> uint32_t * { return lone_bm + w * kLoneLdsWords + k; };
     (void)args_in_kernarg;
     using KArgs = const __attribute__((address_space(4))) TeamArgs;
     auto ka = [&]() -> KArgs * {  // a fresh look at the arguments: what is read through it is not kept alive from an earlier look
@@ -2554,13 +2646,18 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
         __hip_atomic_store(&team_bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&team_dead, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&len_claim, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&adopt_sel, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int w = 0; w < kLoneWaves; w++) {
+            __hip_atomic_store(lone_word(w, kLoneReqWord), kAdoptIdle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(lone_word(w, kLoneStateWord), kLoneRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
     __syncthreads();  // (the only workgroup-wide barrier: before the waves part ways)
     if (kLoneWaves > 0 && wave >= kTeamWaves) {
         // ---- a lone wave: blocks of its own, table in global memory (as the multi-wave kernel's extra waves)
         const uint32_t lw = wave - kTeamWaves;
         for (uint32_t i = lane; i < kGlobLdsWords; i += 64)
-            lone_bm[lw * kGlobLdsWords + i] = 0;
+            lone_bm[lw * kLoneLdsWords + i] = 0;
         for (;;) {
             uint32_t b = next_index();
             if (b >= n_work)
@@ -2576,18 +2673,28 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
             }
             uint16_t *my_glob = as_global<uint16_t>(uni64((uint64_t)(uintptr_t)a->scratch_tables)) +
                                 (size_t)(blockIdx.x * (kLoneWaves > 0 ? kLoneWaves : 1) + lw) * kMaxTable;
-            const HashTab<false> gtab{nullptr, my_glob, lone_bm + lw * kGlobLdsWords + kGlobOccWords, lone_bm + lw * kGlobLdsWords};
+            const HashTab<false> gtab{nullptr, my_glob, lone_bm + lw * kLoneLdsWords + kGlobOccWords, lone_bm + lw * kLoneLdsWords};
             const uint8_t *in_b = as_global<const uint8_t>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
             uint8_t *out_b = as_global<uint8_t>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
             EXP_STARTED(b);
-            const uint32_t op = compress_one_block<0, true>(gtab, in_b, n, out_b, uni(a->flags), lane);
+            const uint32_t op = compress_one_block<0, true, HashTab<false>, true, kMatchPiecesDefault, NoTeam, LoneAdopt>(
+                gtab, in_b, n, out_b, uni(a->flags), lane);
+            if (op == 0xfffffffeu && uni(__hip_atomic_load(lone_word(lw, kLoneReqWord), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kAdoptTaken) {
+                // handed over: the team of this workgroup goes on with the block (the queue is empty: it asked)
+                if (lane == 0)
+                    *lone_word(lw, kLoneRecWord + kAdoptRecBlock) = b;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __hip_atomic_store(lone_word(lw, kLoneStateWord), kLoneHanded, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return;
+            }
             store_len(b, EXP_LONE_MARK(op));
             EXP_FINISHED(b);
         }
+        __hip_atomic_store(lone_word(lw, kLoneStateWord), kLoneLeft, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         return;
     }
     const HashTab<true> tab{lds_tab, nullptr, nullptr, nullptr};
-    WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr, dup_scr + wave * 256u, &team_bar};
+    WaveTeam<kTeamWaves> team{&tokens[0], &tokens[1], wave, nullptr, dup_scr + wave * 256u, &team_bar, nullptr};
     __builtin_amdgcn_s_setprio(kTeamBasePrio);  // (a team's waves go before the lone ones; the token's holder before both)
     // Giving up (a wave of the team stalled for seconds: SZ_TEAM_SPIN_CAP): the wave that gives up raises
     // `team_dead` and every wave of the team leaves the persistent loop at its next look at it -- the barrier's
@@ -2646,6 +2753,112 @@ __global__ __launch_bounds__(64 * kHybridWaves) __attribute__((amdgpu_waves_per_
         }
         if (op != kTeamNotMine && op != kTeamLost)
             EXP_FINISHED(b);
+    }
+    // ---- the end of the launch: adoption.  The queue is empty (a team that left its loop for another reason has raised
+    // `team_dead`); a lone wave of this workgroup that is still inside a block is asked for it, hands it over where its
+    // tile ends and leaves; the team copies its table and goes on from its state -- with an instance of the per-block
+    // code of its own (TeamAdopt), in a loop of its own BEHIND the persistent one: the same steps inside that loop
+    // (inline, or as functions the kernel calls) cost the blocks of the queue 2-8 % in spills and calling conventions
+    // (EXPERIMENTS.md R6.6); what is not on their path cannot.
+    if (kLoneWaves == 0 || (ka()->auto_mode & 2u) != 0)  // (SZ_NO_ADOPT=1: the end of a launch as in round 5, for A/B runs)
+        return;
+    for (;;) {
+        if (uni(__hip_atomic_load(&team_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0)
+            break;
+        if (wave == 0) {
+            uint32_t b0 = 0, sel = 0;  // sel: 1 + the lone wave whose block b0 is
+            for (uint32_t w = 0; w < (uint32_t)kLoneWaves && sel == 0; w++) {
+                uint32_t *const state = lone_word(w, kLoneStateWord), *const req = lone_word(w, kLoneReqWord);
+                uint32_t st = uni(__hip_atomic_load(state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (st == kLoneRunning) {
+                    __hip_atomic_store(req, kAdoptAsked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // (it answers at the end of its tile, ~4 us, or not before the end of its block: a long match, the
+                    // general code, too little left.  Bounded all the same -- well inside the cap of the team mate that
+                    // waits at the barrier below --: the request is withdrawn, one compare-and-swap against the lone wave's
+                    // own, and only a wave that had taken it just then is waited for, for the few stores it is about to make.)
+                    for (uint32_t spin = 0; spin < (SZ_TEAM_SPIN_CAP >> 6) && st == kLoneRunning; spin++) {
+                        __builtin_amdgcn_s_sleep(8);
+                        st = uni(__hip_atomic_load(state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    }
+                    if (st == kLoneRunning) {
+                        uint32_t was = kAdoptIdle;
+                        if (lane == 0) {
+                            uint32_t expect = kAdoptAsked;
+                            (void)__hip_atomic_compare_exchange_strong(req, &expect, kAdoptWithdrawn, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            was = expect;
+                        }
+                        if (uni(was) == kAdoptTaken)
+                            for (uint32_t spin = 0; spin < (1u << 22) && st == kLoneRunning; spin++) {
+                                __builtin_amdgcn_s_sleep(8);
+                                st = uni(__hip_atomic_load(state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            }
+                    }
+                }
+                if (st == kLoneHanded) {
+                    sel = 1u + w;
+                    b0 = uni(__hip_atomic_load(lone_word(w, kLoneRecWord + kAdoptRecBlock), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    __hip_atomic_store(state, kLoneAdopted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __hip_atomic_store(&next_block, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&adopt_sel, sel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        uint32_t lost = team_barrier<kTeamWaves, true>(&team_bar, &team_dead, lane);  // every wave of the team is past the block before
+        const uint32_t b = uni(__hip_atomic_load(&next_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        const uint32_t sel = uni(__hip_atomic_load(&adopt_sel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (wave == 0 && lost == 0) {
+            __hip_atomic_store(&tokens[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&tokens[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&len_claim, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (lost == 0)
+            lost = team_barrier<kTeamWaves, true>(&team_bar, &team_dead, lane);
+        if (__builtin_expect(lost != 0, 0)) {
+            __hip_atomic_store(&team_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wave == 0 && sel != 0)  // (wave 0 took this block from its lone wave: nobody else will report on it)
+                store_len(b, 0xfffffffeu);
+            break;
+        }
+        if (sel == 0)
+            break;  // no lone wave of this workgroup is inside a block any more
+        KArgs *a = ka();
+        const uint32_t n = uni(block_length(a->in_len, a->total_len, a->in_stride, b));
+        EXP_STARTED(b);
+        {
+            // The table the lone wave has built so far becomes the team's: its entries from memory (written through to the
+            // L2 this CU reads from; agent-scope loads, as that wave's own look-ups), a bucket it has not written in this
+            // block -- its table is never cleared -- reads as empty (its bitmap, in this workgroup's LDS, says which).  Both
+            // waves, a slice each; compress_one_block's barrier behind its (skipped) clearing pass stands behind this copy.
+            const uint32_t *occ = lone_bm + (sel - 1u) * kLoneLdsWords;
+            const uint64_t *g = reinterpret_cast<const uint64_t *>(
+                as_global<uint16_t>(uni64((uint64_t)(uintptr_t)a->scratch_tables)) +
+                (size_t)(blockIdx.x * (kLoneWaves > 0 ? kLoneWaves : 1) + (sel - 1u)) * kMaxTable);
+            uint64_t *l = reinterpret_cast<uint64_t *>(lds_tab);
+#pragma unroll 4
+            for (uint32_t i = wave * 64u + lane; i < kMaxTable / 4u; i += 64u * kTeamWaves) {
+                const uint64_t v = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t m4 = occ[i >> 3] >> ((i & 7u) << 2);
+                const uint64_t keep = ((m4 & 1u) ? 0xffffull : 0ull) | ((m4 & 2u) ? 0xffffull << 16 : 0ull) |
+                                      ((m4 & 4u) ? 0xffffull << 32 : 0ull) | ((m4 & 8u) ? 0xffffull << 48 : 0ull);
+                l[i] = v & keep;
+            }
+        }
+        team.arec = lone_word(sel - 1u, kLoneRecWord);
+        const uint8_t *in_b = as_global<const uint8_t>(uni64((uint64_t)(uintptr_t)a->src + (uint64_t)b * a->in_stride));
+        uint8_t *out_b = as_global<uint8_t>(uni64((uint64_t)(uintptr_t)a->dst + (uint64_t)b * a->dst_stride));
+        const uint32_t op = compress_one_block<0, true, HashTab<true>, true, kMatchPiecesDefault, WaveTeam<kTeamWaves>, TeamAdopt>(
+            tab, in_b, n, out_b, uni(a->flags), lane, team);
+        if (op != kTeamNotMine) {  // (a9) one writer, as above
+            const bool mine = __ballot(__hip_atomic_fetch_add(&len_claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) != 0;
+            if (op == kTeamLost)
+                __hip_atomic_store(&team_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (mine)
+                store_len(b, op == kTeamLost ? 0xfffffffeu : EXP_ADOPT_MARK(op));
+            if (op == kTeamLost)
+                break;
+            EXP_FINISHED(b);
+        }
     }
 }
 
@@ -2736,7 +2949,7 @@ static hipError_t launch_any(const void *d_src, uint64_t in_stride, const uint32
             tgrid = tgrid < dual->n_slots ? tgrid : dual->n_slots;
             static_assert(kLoneWaves <= (int)kDualTablesPerGroup, "the workspace has kDualTablesPerGroup tables per workgroup");
             const TeamArgs targs{src, in_stride, d_in_len, total_len, dst, dst_stride, d_out_len, dual->tables, dual->select,
-                                 dual->queue, n_blocks, flags, sampled ? 1u : 0u, queue_half};
+                                 dual->queue, n_blocks, flags, (sampled ? 1u : 0u) | (getenv("SZ_NO_ADOPT") ? 2u : 0u), queue_half};
             if (prof.multi0)
                 (void)hipEventRecord(prof.multi0, stream);
             hipLaunchKernelGGL(compress_blocks_team_kernel, dim3(tgrid), dim3(64 * kHybridWaves), 0, stream, targs);

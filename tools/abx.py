@@ -13,7 +13,7 @@ libs = sys.argv[1].split(",")
 works = [(w.split(":")[0], int(w.split(":")[1])) for w in sys.argv[2].split(",")]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 dev = torch.device("cuda:0")
-modes = [(p.split("@")[1] if "@" in p else None) for p in libs]  # lib.so@dual: SZ_KERNEL=dual for that build's launches
+modes = [(p.split("@")[1] if "@" in p else None) for p in libs]  # lib.so@dual: SZ_KERNEL=dual for that build's launches; lib.so@noadopt: SZ_NO_ADOPT=1
 libs = [p.split("@")[0] for p in libs]
 L = []
 for p in libs:
@@ -29,10 +29,12 @@ for kind, nb in works:
     ol = torch.zeros(nb, dtype=torch.int32, device=dev)
     def run(l):
         m = modes[L.index(l)]
-        if m:
+        os.environ.pop("SZ_KERNEL", None)
+        os.environ.pop("SZ_NO_ADOPT", None)
+        if m == "noadopt":
+            os.environ["SZ_NO_ADOPT"] = "1"
+        elif m:
             os.environ["SZ_KERNEL"] = m
-        else:
-            os.environ.pop("SZ_KERNEL", None)
         rc = l.sz_compress_blocks_hip(src.data_ptr(), 65536, None, nb, dst.data_ptr(), SLOT, ol.data_ptr(), 1, stream)
         assert rc == 0, rc
     for l in L:
