@@ -43,6 +43,9 @@
  *              implementation for differential tests and A/B).
  *              Unset: the sampled choice between `single` and `team` (launches of more than one block per SIMD; smaller
  *              ones: `single`).
+ *   SZ_NO_ADOPT=1  the `team` kernel ends a launch as it did before round 6: a team whose queue is empty does not take
+ *              over the block a lone wave of its workgroup is inside (same bytes, ~2 % slower on compressible launches;
+ *              for A/B runs).
  *   SZ_DECODE_KERNEL  forces a decode kernel: `single` (one wave per stream), `pair` (two:
  *              one parses the next window while the other moves this one's bytes).  Unset: `pair` for launches
  *              of up to 4 096 streams, `single` above.  Same output either way.
