@@ -10,8 +10,8 @@ constexpr uint32_t kFlagBlockVarint = 1u;  // == SZ_FLAG_BLOCK_VARINT
 constexpr int32_t kStatusCorrupt = -74;    // == SZ_ECORRUPT
 constexpr int32_t kStatusNoSpace = -28;    // == SZ_ENOSPC
 
-// Workspace of the multi-wave kernel: n_slots x (waves - 1) hash tables of 16384 x uint16 (zeroed by
-// their wave per block), the launch state and the block queue (cost order); one launch sequence at a time.
+// Workspace of the persistent kernels: n_slots x (waves - 1) hash tables of 16384 x uint16 (never cleared: a
+// bitmap in LDS names the buckets a block has written), the launch state and the block queue (cost order); one launch sequence at a time.
 enum DualMode : uint32_t { kDualAuto = 0, kDualAlways = 2 };
 struct DualScratch {
     uint16_t *tables;
