@@ -8,7 +8,7 @@
 // Mapping to the machine (details at compress_one_block and the two kernels below)
 //   * one 64-lane wavefront per <=64 KiB block; the 16384 x uint16 hash table in LDS (32 KiB: four
 //     blocks per CU = one wave per SIMD) or, for the extra waves of the multi-wave kernel, in a
-//     table of the same shape in global memory (L2), zeroed per block by its wave;
+//     table of the same shape in global memory, never cleared: a bitmap in LDS names the buckets a block has written;
 //   * the greedy parse is serial in the reference; here 64 positions are probed at once -- 64
 //     consecutive bytes ("dense window", scalar walk over the ballot mask, prefix-sum packing of
 //     the elements) or the next 64 probes of the skip schedule ("strided batch") -- and the table
@@ -359,10 +359,10 @@ __device__ __forceinline__ uint32_t sel6(uint32_t r0, uint32_t r1, uint32_t r2, 
 
 // The hash table of one block, in one of two homes:
 //  * LDS, 16384 x uint16, zeroed per block (32 KiB: four of them fit a CU, one per SIMD);
-//  * global memory (L2 / Infinity Cache), the same 16384 x uint16, zeroed per block by its wave (32 KiB
-//    of stores per 64 KiB block).  Used by the extra waves of a SIMD in the multi-wave kernel, for
-//    which no LDS is left.  (A first version had uint32 entries tagged with a generation instead of
-//    the zeroing pass; half the footprint is worth more: these tables live in L2, 4 MiB per XCD.)
+//  * global memory (L2 / Infinity Cache), the same 16384 x uint16, NEVER cleared (round 5): which buckets a block has
+//    written is kept in a 2 KiB bitmap in LDS, the others read as empty.  Used by the lone waves of the team kernel
+//    and the extra waves of the multi-wave kernel, for which no LDS table is left.  (Round 1 had uint32 entries tagged
+//    with a generation, rounds 2-4 a zeroing pass per block; half the footprint was worth more than the tags.)
 // NOT volatile: volatile LDS accesses are not address-space-inferred and compile to FLAT
 // loads/stores with a vmcnt(0) wait after each.  The places that need "really re-read memory"
 // (other lanes of the same store may have won the bucket) use a compiler barrier.
