@@ -714,6 +714,8 @@ int sz_compress_begin(const void *src, size_t n)
     HOST_T(t_1);
     size_t o = 0, first_frag = 0;
     const uint64_t *prev_total = nullptr;
+    uint64_t *pin_tot_dev = nullptr;
+    SZ_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&pin_tot_dev), ws.pin_tot, 0));
     for (uint32_t k = 0; k < K; k++) {
         const size_t bytes = stages[k];
         const uint32_t nbk = (uint32_t)((bytes + SZ_BLOCK_SIZE - 1) / SZ_BLOCK_SIZE);
@@ -723,8 +725,8 @@ int sz_compress_begin(const void *src, size_t n)
         SZ_HIP(hipStreamWaitEvent(ws.stream, ws.ev[2 * k], 0));
         if ((rc = sz_compress_stream_hip(d_in + o, bytes, d_slots, stride, d_len + first_frag, 0, ws.stream)))
             return rc;
-        SZ_HIP(szk::launch_pack_stream(d_slots, stride, d_len + first_frag, nbk, p.nh, d_packed, off_k, ws.stream, prev_total));
-        SZ_HIP(hipMemcpyAsync(ws.pin_tot + k, off_k + nbk, sizeof(uint64_t), hipMemcpyDeviceToHost, ws.stream));
+        // (the stage's running total goes to pinned memory by a store of the scan kernel, not by a copy of 8 bytes: see there)
+        SZ_HIP(szk::launch_pack_stream(d_slots, stride, d_len + first_frag, nbk, p.nh, d_packed, off_k, ws.stream, prev_total, pin_tot_dev + k));
         SZ_HIP(hipEventRecord(ws.ev[2 * k + 1], ws.stream));
         prev_total = off_k + nbk;
         o += bytes;

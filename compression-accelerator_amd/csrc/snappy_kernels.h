@@ -59,9 +59,11 @@ hipError_t launch_compress_stream(const void *d_src, uint64_t n, void *d_slots, 
                                   uint32_t *d_len, uint32_t flags, const DualScratch *dual, hipStream_t stream);
 
 // d_base_from (may be null): read the base from device memory -- the total a pack of the chunk before wrote -- instead.
+// host_total (may be null): a word of pinned, device-visible host memory that receives the stream's total as well
+// (stored by the scan kernel: visible to the host once an event recorded behind the launch has completed).
 hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const uint32_t *d_len,
                               uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
-                              hipStream_t stream, const uint64_t *d_base_from = nullptr);
+                              hipStream_t stream, const uint64_t *d_base_from = nullptr, uint64_t *host_total = nullptr);
 
 hipError_t launch_uncompress_streams(const void *d_src, uint64_t src_stride, const uint32_t *d_src_len,
                                      uint32_t n_streams, void *d_dst, uint64_t dst_stride,

@@ -13,7 +13,8 @@ namespace szk {
 // offset becomes UINT64_MAX, which the gather below skips.
 __global__ __launch_bounds__(1024) void scan_lengths_kernel(const uint32_t *__restrict__ len, uint32_t n,
                                                             uint64_t base, const uint64_t *__restrict__ base_from,
-                                                            uint64_t max_len, uint64_t *__restrict__ off)
+                                                            uint64_t max_len, uint64_t *__restrict__ off,
+                                                            uint64_t *__restrict__ host_total)
 {
     __shared__ uint64_t part[1024];
     __shared__ uint32_t bad;
@@ -52,8 +53,16 @@ __global__ __launch_bounds__(1024) void scan_lengths_kernel(const uint32_t *__re
         off[i] = poisoned ? ~0ull : run;
         run += v > max_len ? 0u : v;
     }
-    if (t == 1023)
-        off[n] = (bad || poisoned) ? ~0ull : base + part[1023];
+    if (t == 1023) {
+        const uint64_t total = (bad || poisoned) ? ~0ull : base + part[1023];
+        off[n] = total;
+        // (sz_compress's pipeline) ... and to a word of pinned host memory, by this store, not by a copy behind the kernel:
+        // an 8-byte copy is a job for a DMA engine, the runtime gives it whichever engine is free when it is submitted, and
+        // when that was the engine with the call's whole input queued on it the total arrived behind the last input byte
+        // -- one call in three took 75 ms instead of 47 (EXPERIMENTS.md R6.9)
+        if (host_total)
+            __hip_atomic_store(host_total, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__restrict__ slots,
@@ -87,9 +96,10 @@ __global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__rest
 
 hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const uint32_t *d_len,
                               uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
-                              hipStream_t stream, const uint64_t *d_base_from)
+                              hipStream_t stream, const uint64_t *d_base_from, uint64_t *host_total)
 {
-    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, stream, d_len, n_blocks, base, d_base_from, slot_stride, d_off);
+    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, stream, d_len, n_blocks, base, d_base_from, slot_stride, d_off,
+                       host_total);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || n_blocks == 0)
         return e;

@@ -38,8 +38,10 @@ int main(int argc, char **argv)
     const size_t cn = (size_t)ftell(f);
     fseek(f, 0, SEEK_SET);
     std::vector<char> corpus(cn);
-    if (fread(corpus.data(), 1, cn, f) != cn)
+    if (cn == 0 || fread(corpus.data(), 1, cn, f) != cn) {  // (an empty corpus would never fill the input)
+        fprintf(stderr, "%s: empty or unreadable\n", argv[2]);
         return 2;
+    }
     const size_t n = (size_t)atoi(argv[3]) << 20;
     const int calls = argc > 4 ? atoi(argv[4]) : 6;
     std::vector<char> in(n), out(bound(n)), back(n);
