@@ -808,14 +808,35 @@ int sz_compress_finish(void *dst, size_t dst_cap, size_t *out_len)
     SyncOnExit drain{ws};  // (declared after the pin: nothing is in flight any more when `dst` is let go)
     HOST_T(t_1);
     uint64_t done = nh;  // bytes of the stream that are in `dst`, or on their way there
+    // The copy out of a stage that did not compress is a KERNEL's (when `dst` is registered, i.e. device-visible): the copy
+    // in keeps the DMA engines to itself.  With both directions on the engines the runtime put them on one engine now and
+    // then (in bench.py's process: in every call on incompressible data) and a call took copy in + copy out instead of the
+    // longer of the two (EXPERIMENTS.md R6.9).  A stage that compressed keeps the engine: its kernel (the team kernel: four
+    // waves of 128 registers per SIMD) leaves a copy kernel no register to run beside it, and its copy out is short.
+    // SZ_COPY_OUT=engine / kernel: one way for every stage.
+    uint8_t *dst_dev = nullptr;
+    int copy_mode = 0;  // 0: by stage, 1: engine, 2: kernel
+    if (pin_dst.ok) {
+        const char *e = getenv("SZ_COPY_OUT");
+        copy_mode = !e ? 0 : strcmp(e, "engine") == 0 ? 1 : strcmp(e, "kernel") == 0 ? 2 : 0;
+        if (copy_mode != 1 && hipHostGetDevicePointer(reinterpret_cast<void **>(&dst_dev), dst, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            dst_dev = nullptr;
+        }
+    }
+    const std::vector<size_t> stages = pipeline_stages(n);  // (the same cut as sz_compress_begin's)
     for (uint32_t k = 0; k < K; k++) {
         SZ_HIP(hipEventSynchronize(ws.ev[2 * k + 1]));
-        const uint64_t total = ws.pin_tot[k];
+        const uint64_t total = *const_cast<volatile uint64_t *>(ws.pin_tot + k);
         if (total == ~0ull)  // a fragment came back with an error marker instead of a length
             return SZ_EHIP;
         if (total > dst_cap)
             return SZ_ENOSPC;
-        SZ_HIP(hipMemcpyAsync(h_dst + done, d_packed + done, total - done, hipMemcpyDeviceToHost, ws.s_out));
+        const bool by_kernel = dst_dev && (copy_mode == 2 || (k < stages.size() && (total - done) * 8 >= (uint64_t)stages[k] * 7));
+        if (by_kernel)
+            SZ_HIP(szk::launch_copy_out(dst_dev + done, d_packed + done, total - done, ws.s_out));
+        else
+            SZ_HIP(hipMemcpyAsync(h_dst + done, d_packed + done, total - done, hipMemcpyDeviceToHost, ws.s_out));
         done = total;
     }
     SZ_HIP(hipStreamSynchronize(ws.s_out));

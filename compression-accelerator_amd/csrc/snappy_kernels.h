@@ -65,6 +65,9 @@ hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const u
                               uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
                               hipStream_t stream, const uint64_t *d_base_from = nullptr, uint64_t *host_total = nullptr);
 
+// n bytes from device memory to a device-visible address of (registered) host memory, by a kernel (no DMA engine)
+hipError_t launch_copy_out(void *dst_dev, const void *d_src, uint64_t n, hipStream_t stream);
+
 hipError_t launch_uncompress_streams(const void *d_src, uint64_t src_stride, const uint32_t *d_src_len,
                                      uint32_t n_streams, void *d_dst, uint64_t dst_stride,
                                      uint32_t *d_out_len, int32_t *d_status, hipStream_t stream);

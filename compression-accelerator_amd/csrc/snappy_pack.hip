@@ -94,6 +94,38 @@ __global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t *__rest
         d[done + t] = s[done + t];
 }
 
+// A stretch of the packed stream written straight into the caller's (registered, device-visible) host buffer by a kernel
+// instead of a DMA engine: 16-byte stores on dst-aligned addresses, a wave's store = 1 KiB in one piece over the link.
+// (sz_compress's pipeline: with both directions on the DMA engines the runtime now and then put them on ONE engine --
+// its choice, made anew after every synchronisation -- and the copy out waited for the whole copy in; EXPERIMENTS.md R6.9.)
+__global__ __launch_bounds__(256) void copy_out_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint64_t n)
+{
+    const uint64_t head = (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u;
+    const uint64_t h = head < n ? head : n;
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (uint64_t)gridDim.x * 256;
+    if (tid < h)
+        dst[tid] = src[tid];
+    const uint64_t nvec = (n - h) >> 4;
+    uint8_t *d = dst + h;
+    const uint8_t *s = src + h;
+    for (uint64_t i = tid; i < nvec; i += nthreads)
+        __builtin_nontemporal_store(ld128(s + 16 * i), reinterpret_cast<u32x4 *>(d + 16 * i));
+    const uint64_t done = nvec << 4, tail = (n - h) & 15u;
+    if (tid < tail)
+        d[done + tid] = s[done + tid];
+}
+
+hipError_t launch_copy_out(void *dst_dev, const void *d_src, uint64_t n, hipStream_t stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    const uint64_t want = (n / 16 + 255) / 256 + 1;
+    const uint32_t grid = (uint32_t)(want < 128 ? want : 128);  // (32 ... 2 048 workgroups: 51.3-53.0 ms per 2 GiB call, the link's business)
+    hipLaunchKernelGGL(copy_out_kernel, dim3(grid), dim3(256), 0, stream, static_cast<uint8_t *>(dst_dev),
+                       static_cast<const uint8_t *>(d_src), n);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_stream(const void *d_slots, uint64_t slot_stride, const uint32_t *d_len,
                               uint32_t n_blocks, uint64_t base, void *d_packed, uint64_t *d_off,
                               hipStream_t stream, const uint64_t *d_base_from, uint64_t *host_total)

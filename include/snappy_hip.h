@@ -52,6 +52,8 @@
  *   SZ_SERIAL_UNCOMPRESS=1  makes sz_uncompress skip the parallel fragment index (single-wavefront decode).
  *   SZ_NO_HOST_REGISTER=1   sz_compress / sz_uncompress on large buffers do not register the caller's memory for DMA
  *                           (the runtime's pageable copies instead: same bytes, slower).
+ *   SZ_COPY_OUT=engine|kernel  sz_compress on large buffers copies every stage out with the DMA engines / with a kernel
+ *                           (default: a kernel for stages that did not compress, the engines for the others).
  *   SZ_TEST_SEG_SHIFT       a hook of the test-suite (segment size of the fragment index).
  *   SZ_DEBUG_FLAGS          only read by diagnostic builds (-DSZ_ABLATION: timing ablations with wrong output).
  */

@@ -58,17 +58,22 @@ def test_host_compress_is_snappy_compress(mode, monkeypatch):
 
 
 @pytest.mark.timeout(300, method="thread")
-@pytest.mark.parametrize("register", ["registered", "pageable", "read_only_mapping"])
+@pytest.mark.parametrize("register", ["registered", "pageable", "read_only_mapping", "copy_out_kernel", "copy_out_engine"])
 def test_host_compress_pipeline_of_large_buffers(register, monkeypatch, tmp_path):
     """sz_compress on a buffer of 128 MiB or more runs as a pipeline of stages (copy in | compress + pack | copy out, three
     streams, the caller's memory registered for DMA for the length of the call): three stages with a ragged last one,
     text, incompressible and low-entropy data side by side, bytes == the oracle's snappy::Compress.  The same without
     registration (SZ_NO_HOST_REGISTER: the runtime's pageable copies), from a read-only file mapping (registration
     of PROT_READ pages fails or needs the read-only flag), with a `dst` that is too small (SZ_ENOSPC, and the next call
-    is unharmed), and back through sz_uncompress."""
+    is unharmed), and back through sz_uncompress.  A stage that did not compress is copied out by a kernel that stores
+    into the registered `dst`, the others by the DMA engines (round 6): `SZ_COPY_OUT=kernel` / `engine` take one way for
+    every stage (the kernel's stretches then begin at every alignment)."""
     import mmap
+    monkeypatch.delenv("SZ_COPY_OUT", raising=False)
     if register == "pageable":
         monkeypatch.setenv("SZ_NO_HOST_REGISTER", "1")
+    if register.startswith("copy_out_"):
+        monkeypatch.setenv("SZ_COPY_OUT", register[len("copy_out_"):])
     P = pkg()
     L = P.lib()
     mtg, rnd = fuzzgen.corpus("mtg"), fuzzgen.corpus("random_ascii")
