@@ -45,6 +45,10 @@ static constexpr uint32_t kInputMargin = 15u;  // CompressionAccelerator.scala:7
 // walk -- SZ_SPEC_MODE 1..3, rounds 2 and 5 -- and a second visit's candidates re-read from memory -- SZ_REVISIT_REGS=0,
 // rounds 2-4 --: spec_heads_and_revisit_from_memory.patch; EXPERIMENTS.md R5.4.)
 static constexpr uint32_t kFastMargin = 128u;  // the fast dense path stays this far from the last probe position
+#ifndef SZ_SKIP_DEAD_LANES
+#define SZ_SKIP_DEAD_LANES 1
+#endif
+static constexpr bool kSkipDeadLanes = SZ_SKIP_DEAD_LANES != 0;  // global-table waves: no look-up, no candidate string for the lanes below a tile's entry
 
 // Probe schedule of the scan loop after a (re)start: off[k] = distance of the k-th probe from the
 // first one.  skip_0 = 32, off_{k+1} = off_k + (skip_k >> 5), skip_{k+1} = skip_k + (skip_k >> 5).
@@ -1445,8 +1449,23 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         }
                         asm volatile("" ::: "memory");
                     }
-                    ncand = tab.get(nh);
-                    head_loads();
+                    if constexpr (!Tab::kInLds && kSkipDeadLanes) {
+                        // (round 6) A table in memory: the lanes below the one the parse enters the tile at -- the tail of
+                        // the copy that crossed into it: 5.9 lanes of 64 on text -- are never probed, and that is known
+                        // here: no look-up and no candidate string for them (9 % of a lone wave's requests over the
+                        // fabric, which is what bounds it: EXPERIMENTS.md R6.7).  Their hashes are still needed (the
+                        // insert of P-1, the commit); their hit bits are masked wherever the tile's are used (`keep`).
+                        ncand = 0;
+                        nc = nc2 = u32x4{0, 0, 0, 0};
+                        if (lane >= e2v) {
+                            ncand = tab.get(nh);
+                            head_loads();
+                        }
+                        UNIFORM_JOIN();
+                    } else {
+                        ncand = tab.get(nh);
+                        head_loads();
+                    }
                 };
                 for (;;) {  // ================================================ one tile per trip
                     // ---- (A) the elements closed inside the tile that is being left (all its visits)
