@@ -392,13 +392,14 @@ struct HashTab {
     // ~14 are probed; a third to a half of them find an empty bucket: that many fewer 64-byte reads over the fabric,
     // where every look-up of these tables is a miss in the L2), and the table in memory is never cleared: what an
     // earlier block left in a bucket is not read before this block has written the bucket.
-    __device__ __forceinline__ uint32_t get(uint32_t h) const
+    // (`wanted` = false: a lane whose look-up nobody will use -- it reads as an empty bucket, without a request)
+    __device__ __forceinline__ uint32_t get(uint32_t h, bool wanted = true) const
     {
         if (in_lds)
             return __hip_atomic_load(lds + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         const uint32_t w = __hip_atomic_load(occ + (h >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         uint32_t v = 0;
-        if ((w >> (h & 31u)) & 1u)
+        if (((w >> (h & 31u)) & 1u) != 0 && wanted)
             v = __hip_atomic_load(glob + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return v;
     }
@@ -1455,13 +1456,10 @@ __device__ __forceinline__ uint32_t compress_one_block(const Tab &tab, const uin
                         // here: no look-up and no candidate string for them (9 % of a lone wave's requests over the
                         // fabric, which is what bounds it: EXPERIMENTS.md R6.7).  Their hashes are still needed (the
                         // insert of P-1, the commit); their hit bits are masked wherever the tile's are used (`keep`).
-                        ncand = 0;
-                        nc = nc2 = u32x4{0, 0, 0, 0};
-                        if (lane >= e2v) {
-                            ncand = tab.get(nh);
-                            head_loads();
-                        }
-                        UNIFORM_JOIN();
+                        // (one predicate with the "bucket is occupied" test of the look-up; a dead lane's candidate is
+                        // position 0 like an empty bucket's: its string is the block's first line, which every such lane shares)
+                        ncand = tab.get(nh, lane >= e2v);
+                        head_loads();
                     } else {
                         ncand = tab.get(nh);
                         head_loads();
